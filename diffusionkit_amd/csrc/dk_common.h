@@ -1,0 +1,67 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 storage
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define DK_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 (NaN not special-cased: the hot path never produces NaN
+// from finite inputs; inf stays inf).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack2bf(uint32_t v, float& lo, float& hi) {
+  lo = __uint_as_float(v << 16);
+  hi = __uint_as_float(v & 0xffff0000u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- host side -----------------------------------------------------------------------
+#include <string>
+void dk_set_error(const std::string& msg);
+#define DK_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      dk_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+      return -2;                                                                        \
+    }                                                                                   \
+  } while (0)
+#define DK_REQUIRE(cond, msg)                                                           \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      dk_set_error(std::string("requirement failed: ") + #cond + " -- " + (msg));       \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)

@@ -1,0 +1,82 @@
+// Internal launcher declarations shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include "../../include/dk_hip.h"
+#include "dk_common.h"
+
+// ---- GEMM / implicit-GEMM conv ---------------------------------------------------------
+// C[m, n] = epi(alpha * sum_k A[m, k] * W[n, k] + bias[n])   (bf16 in, fp32 accumulate, bf16 out)
+// Logical row m maps to physical row (m / seg_len) * seg_stride + (m % seg_len); this is how a
+// stream (text rows / image rows of a joint [B, S, h] buffer) is addressed without copies.
+// epilogue codes: DK_EPI_* in include/dk_hip.h
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* W;
+  bf16_t* C;
+  const bf16_t* bias;  // [N] or null
+  const bf16_t* gate;  // [n_batch, gate_stride] or null
+  const bf16_t* res;   // same row mapping as C, leading dim ldr
+  int M, N, K;
+  int lda, ldc, ldr;
+  int a_seg_len, a_seg_stride;
+  int c_seg_len, c_seg_stride;
+  int r_seg_len, r_seg_stride;
+  int gate_seg_len, gate_stride;
+  float alpha;
+  int epi;
+  // implicit-GEMM 3x3 conv (pad 1, stride 1) over NHWC input; M = cB*cH*cW output pixels,
+  // K = 9*cC. If ups != 0 the conv input is the nearest-neighbour x2 upsampling of the stored
+  // [cB, cH/2, cW/2, cC] tensor (vae.py:20-25 folded into the gather).
+  int conv;
+  int cB, cH, cW, cC, ups;
+  const bf16_t* zeros;  // >= 128 B of zeros (padding taps)
+};
+int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// ---- attention -------------------------------------------------------------------------
+struct AttnParams {
+  const bf16_t* Q;  // row s of batch b: Q + (b*S + s)*ld + head*D
+  const bf16_t* K;
+  const bf16_t* V;
+  bf16_t* O;  // O + (b*S + s)*ldo + head*D
+  int B, H, S, D;
+  int ld, ldo;
+  float scale;
+};
+int dk_launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ---- elementwise / normalisation ---------------------------------------------------------
+// out[m, :] = bf16( LN(x[m, :]) * bf16(1 + scale[b, :]) + shift[b, :] ), b = m / seg_len
+int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M, int h,
+                          const bf16_t* shift, const bf16_t* scale, int mod_stride, int seg_len,
+                          int x_seg_len, int x_seg_stride, float eps, hipStream_t stream);
+// in-place per-head RMSNorm (learned weight) + RoPE on the q and k column groups of a QKV buffer
+int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, int H, int D,
+                           const bf16_t* qw, const bf16_t* kw, float eps, const float* rope,
+                           int row_seg_len, int row_seg_stride, int pos_off, int S_pos,
+                           hipStream_t stream);
+int dk_launch_silu(const bf16_t* x, bf16_t* y, long n, hipStream_t stream);
+int dk_launch_add(const bf16_t* a, const bf16_t* b, int b_rows, bf16_t* y, int rows, int cols, hipStream_t stream);
+int dk_launch_timestep_embedding(const float* t, int n, int rep, int dim, float max_period, int embed_dtype,
+                                 bf16_t* out, hipStream_t stream);
+int dk_launch_rope_table(float* table, int S_txt, int gh, int gw, const int* axes, int n_axes, float theta,
+                         hipStream_t stream);
+int dk_launch_f32_to_bf16(const float* x, bf16_t* y, long n, hipStream_t stream);
+int dk_launch_affine_f32(const float* x, float* y, long n, float a, float b, hipStream_t stream);
+// latent [n_img, Hl, Wl, C] fp32 -> tokens [B, S_i, p*p*C] bf16 (B = n_img * dup)
+int dk_launch_latent_to_tokens(const float* x, bf16_t* tok, int n_img, int dup, int Hl, int Wl, int C, int p,
+                               int reshape_order, hipStream_t stream);
+// fused x0-prediction + CFG + Euler update (+ re-patchify for the next step)
+int dk_launch_euler_step(float* x, const bf16_t* model_out, int ld_out, bf16_t* tok, int n_img, int cfg_on,
+                         int Hl, int Wl, int C, int p, int reshape_order, float sigma, float sigma_next,
+                         float cfg_weight, hipStream_t stream);
+
+// ---- VAE ops -------------------------------------------------------------------------------
+int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk,
+                              float* mean_rstd, float eps, hipStream_t stream);
+int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,
+                              const bf16_t* gamma, const bf16_t* beta, int do_silu, hipStream_t stream);
+int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t stream);
+int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream);
+int dk_launch_pad_channels(const float* x, bf16_t* y, long npix, int C, int Cpad, hipStream_t stream);
+int dk_launch_image_post(const bf16_t* x, int ldx, float* img, unsigned char* u8, long npix, hipStream_t stream);

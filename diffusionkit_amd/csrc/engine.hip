@@ -1,0 +1,699 @@
+// C-ABI layer (include/dk_hip.h) + the host-side MMDiT / VAE-decoder engines that sequence the
+// gfx950 kernels.  Host code only: no kernels are defined here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dk_hip.h"
+#include "dk_kernels.h"
+
+static thread_local std::string g_last_error;
+void dk_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" int dk_abi_version(void) { return DK_ABI_VERSION; }
+extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
+
+static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// operator-level wrappers
+// ---------------------------------------------------------------------------------------------
+static GemmParams gemm_params_from_desc(const dk_gemm_desc* d) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)d->A; p.W = (const bf16_t*)d->W; p.C = (bf16_t*)d->C;
+  p.bias = (const bf16_t*)d->bias; p.gate = (const bf16_t*)d->gate; p.res = (const bf16_t*)d->res;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.a_seg_len = d->a_seg_len > 0 ? d->a_seg_len : d->M; p.a_seg_stride = d->a_seg_stride;
+  p.c_seg_len = d->c_seg_len > 0 ? d->c_seg_len : d->M; p.c_seg_stride = d->c_seg_stride;
+  p.r_seg_len = d->r_seg_len > 0 ? d->r_seg_len : d->M; p.r_seg_stride = d->r_seg_stride;
+  p.gate_seg_len = d->gate_seg_len > 0 ? d->gate_seg_len : d->M; p.gate_stride = d->gate_stride;
+  p.alpha = d->alpha; p.epi = d->epilogue;
+  return p;
+}
+
+extern "C" int dk_gemm_bf16(const dk_gemm_desc* d, void* stream) {
+  DK_REQUIRE(d != nullptr, "null descriptor");
+  return dk_launch_gemm(gemm_params_from_desc(d), S_(stream));
+}
+
+extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) {
+  DK_REQUIRE(d != nullptr, "null descriptor");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)d->x; p.W = (const bf16_t*)d->w; p.C = (bf16_t*)d->y;
+  p.bias = (const bf16_t*)d->bias; p.res = (const bf16_t*)d->res;
+  p.M = d->B * d->H * d->W; p.N = d->O; p.K = 9 * d->C;
+  p.lda = d->C; p.ldc = d->ldy; p.ldr = d->ldr;
+  p.a_seg_len = p.c_seg_len = p.r_seg_len = p.gate_seg_len = p.M;
+  p.alpha = 1.0f; p.epi = d->epilogue;
+  p.conv = 1; p.cB = d->B; p.cH = d->H; p.cW = d->W; p.cC = d->C; p.ups = d->upsample;
+  p.zeros = (const bf16_t*)d->zeros;
+  if (d->upsample) DK_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "upsampled conv needs even output size");
+  return dk_launch_gemm(p, S_(stream));
+}
+
+extern "C" int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t S,
+                                 int32_t D, int32_t ld, int32_t ldo, float scale, void* stream) {
+  AttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)out;
+  p.B = B; p.H = H; p.S = S; p.D = D; p.ld = ld; p.ldo = ldo; p.scale = scale;
+  return dk_launch_attention(p, S_(stream));
+}
+
+extern "C" int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t M, int32_t h, const void* shift,
+                                   const void* scale, int32_t mod_stride, int32_t mod_seg_len, int32_t x_seg_len,
+                                   int32_t x_seg_stride, float eps, void* stream) {
+  return dk_launch_ln_modulate((const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, h, (const bf16_t*)shift, (const bf16_t*)scale,
+                               mod_stride, mod_seg_len > 0 ? mod_seg_len : M, x_seg_len > 0 ? x_seg_len : M, x_seg_stride,
+                               eps, S_(stream));
+}
+
+extern "C" int dk_qk_norm_rope_bf16(void* qkv, int32_t ld, int32_t q_off, int32_t k_off, int32_t rows, int32_t H, int32_t D,
+                                    const void* q_weight, const void* k_weight, float eps, const float* rope_table,
+                                    int32_t row_seg_len, int32_t row_seg_stride, int32_t pos_off, void* stream) {
+  return dk_launch_qk_norm_rope((bf16_t*)qkv, ld, q_off, k_off, rows, H, D, (const bf16_t*)q_weight, (const bf16_t*)k_weight,
+                                eps, rope_table, row_seg_len > 0 ? row_seg_len : rows, row_seg_stride, pos_off, 0, S_(stream));
+}
+
+extern "C" int dk_rope_table_f32(float* table, int32_t S_txt, int32_t gh, int32_t gw, const int32_t* axes_dim, int32_t n_axes,
+                                 float theta, void* stream) {
+  return dk_launch_rope_table(table, S_txt, gh, gw, axes_dim, n_axes, theta, S_(stream));
+}
+
+extern "C" int dk_timestep_embedding_bf16(const float* t_dev, int32_t n, int32_t dim, float max_period, int32_t embed_dtype,
+                                          void* out, void* stream) {
+  return dk_launch_timestep_embedding(t_dev, n, 1, dim, max_period, embed_dtype, (bf16_t*)out, S_(stream));
+}
+
+extern "C" int dk_latent_to_tokens(const float* x, void* tokens, int32_t n_img, int32_t dup, int32_t Hl, int32_t Wl, int32_t C,
+                                   int32_t p, int32_t reshape_order, void* stream) {
+  DK_REQUIRE(Hl % p == 0 && Wl % p == 0, "latent size must be divisible by the patch size");
+  return dk_launch_latent_to_tokens(x, (bf16_t*)tokens, n_img, dup, Hl, Wl, C, p, reshape_order, S_(stream));
+}
+
+extern "C" int dk_euler_cfg_step(float* x, const void* model_out, int32_t ld_out, void* tokens, int32_t n_img, int32_t cfg_on,
+                                 int32_t Hl, int32_t Wl, int32_t C, int32_t p, int32_t reshape_order, float sigma,
+                                 float sigma_next, float cfg_weight, void* stream) {
+  DK_REQUIRE(sigma != 0.0f, "sigma must be non-zero");
+  return dk_launch_euler_step(x, (const bf16_t*)model_out, ld_out, (bf16_t*)tokens, n_img, cfg_on, Hl, Wl, C, p, reshape_order,
+                              sigma, sigma_next, cfg_weight, S_(stream));
+}
+
+extern "C" int dk_affine_f32(const float* x, float* y, int64_t n, float a, float b, void* stream) {
+  return dk_launch_affine_f32(x, y, (long)n, a, b, S_(stream));
+}
+
+static int gn_nchunk(long HW, int C) {
+  const long ppi = 256 / (C / 8);
+  long n = HW / (ppi * 8);
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+extern "C" size_t dk_groupnorm_scratch_floats(int32_t B, int32_t G) { return (size_t)B * 1024 * 2 * G + (size_t)B * G * 2; }
+extern "C" int dk_groupnorm_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* gamma,
+                                 const void* beta, float eps, int32_t fuse_silu, float* scratch, void* stream) {
+  const int nchunk = gn_nchunk((long)HW, C);
+  float* mean_rstd = scratch + (size_t)B * 1024 * 2 * G;
+  int rc = dk_launch_groupnorm_stats((const bf16_t*)x, B, (long)HW, C, G, scratch, nchunk, mean_rstd, eps, S_(stream));
+  if (rc) return rc;
+  return dk_launch_groupnorm_apply((const bf16_t*)x, (bf16_t*)y, B, (long)HW, C, G, mean_rstd, (const bf16_t*)gamma,
+                                   (const bf16_t*)beta, fuse_silu, S_(stream));
+}
+
+extern "C" int dk_softmax_rows_bf16(void* x, int32_t rows, int32_t cols, int32_t ld, void* stream) {
+  return dk_launch_softmax_rows((bf16_t*)x, rows, cols, ld, S_(stream));
+}
+extern "C" int dk_transpose_bf16(const void* x, void* y, int32_t R, int32_t C, void* stream) {
+  return dk_launch_transpose((const bf16_t*)x, (bf16_t*)y, R, C, S_(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by the engines
+// ---------------------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off, cap;
+  bool dry;
+  Carver(void* b, size_t c) : base((char*)b), off(0), cap(c), dry(b == nullptr) {}
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = dry ? nullptr : (void*)(base + off);
+    off += bytes;
+    return p;
+  }
+};
+
+static int linear_call(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
+                       bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
+                       const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
+                       int r_seg_stride, hipStream_t st) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.gate = gate; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+  p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride;
+  p.c_seg_len = c_seg_len; p.c_seg_stride = c_seg_stride;
+  p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
+  p.gate_seg_len = gate_seg_len > 0 ? gate_seg_len : M; p.gate_stride = gate_stride;
+  p.alpha = 1.0f; p.epi = epi;
+  return dk_launch_gemm(p, st);
+}
+// plain [M,K] x [N,K]^T -> [M,N]
+static int linear_plain(const bf16_t* A, const bf16_t* W, const bf16_t* bias, bf16_t* C, int M, int N, int K, int epi,
+                        hipStream_t st) {
+  return linear_call(A, K, M, 0, W, bias, C, N, M, 0, M, N, K, epi, nullptr, 0, 0, nullptr, 0, 0, 0, st);
+}
+
+#define DK_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// MMDiT engine
+// ---------------------------------------------------------------------------------------------
+struct StreamW {  // one TransformerBlock's weights (mmdit.py:395-438)
+  const bf16_t *qkv_w = nullptr, *qkv_b = nullptr, *qn = nullptr, *kn = nullptr;
+  const bf16_t *o_w = nullptr, *o_b = nullptr, *fc1_w = nullptr, *fc1_b = nullptr, *fc2_w = nullptr, *fc2_b = nullptr;
+  const bf16_t *l2_w = nullptr, *l2_b = nullptr;  // single blocks: [h, 5h] = [o_proj | fc2]
+};
+
+struct dk_mmdit {
+  dk_mmdit_config cfg;
+  std::unordered_map<std::string, const void*> named;
+  bool resolved = false;
+  // resolved weights
+  const bf16_t *xemb_w, *xemb_b, *pos_w, *ctx_w, *ctx_b, *y0_w, *y0_b, *y2_w, *y2_b, *t0_w, *t0_b, *t2_w, *t2_b;
+  const bf16_t *adaln_w, *adaln_b, *final_w, *final_b;
+  std::vector<StreamW> dimg, dtxt, single;
+  // shape
+  int B = 0, Hl = 0, Wl = 0, S_t = 0, S_i = 0, S = 0, n_t = 0;
+  bool prepared = false, mod_ready = false;
+  // workspace views
+  bf16_t *X, *XN, *QKV, *ATT, *CAT, *HID, *MOD, *POS;
+  bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
+  float *rope, *tdev;
+
+  int h() const { return cfg.hidden_size; }
+  int D() const { return cfg.hidden_size / cfg.num_heads; }
+  int F() const { return cfg.patch_size * cfg.patch_size * cfg.vae_latent_dim; }
+  bool txt_skipped(int i) const { return i == cfg.depth_multimodal - 1 && cfg.depth_unified < 1; }
+  int mod_rows() const {
+    int n = 0;
+    for (int i = 0; i < cfg.depth_multimodal; ++i) n += 6 + (txt_skipped(i) ? 2 : 6);
+    return n + 3 * cfg.depth_unified + 2;
+  }
+  int mod_offset(int kind, int index) const {
+    int n = 0;
+    for (int i = 0; i < cfg.depth_multimodal; ++i) {
+      if (kind == 0 && i == index) return n;
+      n += 6;
+      if (kind == 1 && i == index) return n;
+      n += txt_skipped(i) ? 2 : 6;
+    }
+    for (int i = 0; i < cfg.depth_unified; ++i) {
+      if (kind == 2 && i == index) return n;
+      n += 3;
+    }
+    if (kind == 3) return n;
+    return -1;
+  }
+};
+
+extern "C" int dk_mmdit_create(const dk_mmdit_config* cfg, dk_mmdit** out) {
+  DK_REQUIRE(cfg && out, "null argument");
+  DK_REQUIRE(cfg->hidden_size % cfg->num_heads == 0, "hidden_size must be divisible by num_heads");
+  const int D = cfg->hidden_size / cfg->num_heads;
+  DK_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+  DK_REQUIRE(cfg->hidden_size % 64 == 0, "hidden_size must be a multiple of 64");
+  DK_REQUIRE((cfg->patch_size * cfg->patch_size * cfg->vae_latent_dim) % 64 == 0, "patch feature size must be a multiple of 64");
+  DK_REQUIRE(cfg->token_level_text_embed_dim % 64 == 0 && cfg->pooled_text_embed_dim % 64 == 0 &&
+                 cfg->frequency_embed_dim % 64 == 0,
+             "embedding dims must be multiples of 64");
+  if (cfg->use_rope) {
+    int half = 0;
+    for (int i = 0; i < cfg->n_rope_axes; ++i) half += cfg->rope_axes_dim[i] / 2;
+    DK_REQUIRE(half * 2 == D, "rope axes must sum to head_dim");
+  }
+  dk_mmdit* m = new dk_mmdit();
+  m->cfg = *cfg;
+  *out = m;
+  return 0;
+}
+extern "C" void dk_mmdit_destroy(dk_mmdit* m) { delete m; }
+
+extern "C" int dk_mmdit_bind(dk_mmdit* m, const char* name, const void* dev_ptr) {
+  DK_REQUIRE(m && name && dev_ptr, "null argument");
+  m->named[name] = dev_ptr;
+  m->resolved = false;
+  return 0;
+}
+extern "C" int dk_mmdit_mod_rows(const dk_mmdit* m) { return m->mod_rows(); }
+extern "C" int dk_mmdit_mod_offset(const dk_mmdit* m, int32_t kind, int32_t index) { return m->mod_offset(kind, index); }
+
+static int need(const std::unordered_map<std::string, const void*>& named, const std::string& name, const bf16_t** out,
+                bool optional = false) {
+  auto it = named.find(name);
+  if (it == named.end()) {
+    *out = nullptr;
+    if (optional) return 0;
+    dk_set_error("weight not bound: " + name);
+    return -3;
+  }
+  *out = (const bf16_t*)it->second;
+  return 0;
+}
+
+static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool single, bool skip_post) {
+  const auto& n = m->named;
+  DK_TRY(need(n, p + ".attn.qkv.weight", &w.qkv_w));
+  DK_TRY(need(n, p + ".attn.qkv.bias", &w.qkv_b));
+  if (m->cfg.use_qk_norm) {
+    DK_TRY(need(n, p + ".qk_norm.q_norm.weight", &w.qn));
+    DK_TRY(need(n, p + ".qk_norm.k_norm.weight", &w.kn));
+  }
+  if (skip_post) return 0;
+  DK_TRY(need(n, p + ".mlp.fc1.weight", &w.fc1_w));
+  DK_TRY(need(n, p + ".mlp.fc1.bias", &w.fc1_b));
+  if (single) {
+    DK_TRY(need(n, p + ".linear2.weight", &w.l2_w));
+    DK_TRY(need(n, p + ".linear2.bias", &w.l2_b));
+  } else {
+    DK_TRY(need(n, p + ".attn.o_proj.weight", &w.o_w));
+    DK_TRY(need(n, p + ".attn.o_proj.bias", &w.o_b));
+    DK_TRY(need(n, p + ".mlp.fc2.weight", &w.fc2_w));
+    DK_TRY(need(n, p + ".mlp.fc2.bias", &w.fc2_b));
+  }
+  return 0;
+}
+
+static int mmdit_resolve(dk_mmdit* m) {
+  if (m->resolved) return 0;
+  const auto& n = m->named;
+  DK_TRY(need(n, "x_embedder.proj.weight", &m->xemb_w));
+  DK_TRY(need(n, "x_embedder.proj.bias", &m->xemb_b));
+  DK_TRY(need(n, "x_pos_embedder.pos_embed.weight", &m->pos_w, !m->cfg.use_pos_embed));
+  DK_TRY(need(n, "context_embedder.weight", &m->ctx_w));
+  DK_TRY(need(n, "context_embedder.bias", &m->ctx_b));
+  DK_TRY(need(n, "y_embedder.mlp.layers.0.weight", &m->y0_w));
+  DK_TRY(need(n, "y_embedder.mlp.layers.0.bias", &m->y0_b));
+  DK_TRY(need(n, "y_embedder.mlp.layers.2.weight", &m->y2_w));
+  DK_TRY(need(n, "y_embedder.mlp.layers.2.bias", &m->y2_b));
+  DK_TRY(need(n, "t_embedder.mlp.layers.0.weight", &m->t0_w));
+  DK_TRY(need(n, "t_embedder.mlp.layers.0.bias", &m->t0_b));
+  DK_TRY(need(n, "t_embedder.mlp.layers.2.weight", &m->t2_w));
+  DK_TRY(need(n, "t_embedder.mlp.layers.2.bias", &m->t2_b));
+  DK_TRY(need(n, "adaLN.weight", &m->adaln_w));
+  DK_TRY(need(n, "adaLN.bias", &m->adaln_b));
+  DK_TRY(need(n, "final_layer.linear.weight", &m->final_w));
+  DK_TRY(need(n, "final_layer.linear.bias", &m->final_b));
+  m->dimg.assign(m->cfg.depth_multimodal, StreamW());
+  m->dtxt.assign(m->cfg.depth_multimodal, StreamW());
+  m->single.assign(m->cfg.depth_unified, StreamW());
+  for (int i = 0; i < m->cfg.depth_multimodal; ++i) {
+    const std::string b = "multimodal_transformer_blocks." + std::to_string(i);
+    DK_TRY(resolve_stream(m, b + ".image_transformer_block", m->dimg[i], false, false));
+    DK_TRY(resolve_stream(m, b + ".text_transformer_block", m->dtxt[i], false, m->txt_skipped(i)));
+  }
+  for (int i = 0; i < m->cfg.depth_unified; ++i)
+    DK_TRY(resolve_stream(m, "unified_transformer_blocks." + std::to_string(i) + ".transformer_block", m->single[i], true, false));
+  m->resolved = true;
+  return 0;
+}
+
+static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t, int n_t) {
+  const int h = m->h(), p = m->cfg.patch_size;
+  const int S_i = (Hl / p) * (Wl / p), S = S_t + S_i;
+  const size_t BS = (size_t)B * S;
+  m->X = (bf16_t*)c.take(BS * h * 2);
+  m->XN = (bf16_t*)c.take(BS * h * 2);
+  m->QKV = (bf16_t*)c.take(BS * 3 * h * 2);
+  m->ATT = (bf16_t*)c.take(BS * h * 2);
+  const size_t hid = (size_t)B * (S_i > S_t ? S_i : S_t) * m->cfg.mlp_ratio * h * 2;
+  const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)(1 + m->cfg.mlp_ratio) * h * 2 : 0;
+  m->CAT = (bf16_t*)c.take(cat > hid ? cat : hid);  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
+  m->HID = m->CAT;
+  m->MOD = (bf16_t*)c.take((size_t)n_t * B * m->mod_rows() * h * 2);
+  m->POS = (bf16_t*)c.take(m->cfg.use_pos_embed ? (size_t)S_i * h * 2 : 0);
+  m->temb = (bf16_t*)c.take((size_t)n_t * m->cfg.frequency_embed_dim * 2);
+  m->t1 = (bf16_t*)c.take((size_t)n_t * h * 2);
+  m->tvec = (bf16_t*)c.take((size_t)n_t * h * 2);
+  m->y1 = (bf16_t*)c.take((size_t)B * h * 2);
+  m->yvec = (bf16_t*)c.take((size_t)B * h * 2);
+  m->vec = (bf16_t*)c.take((size_t)n_t * B * h * 2);
+  m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
+  m->tdev = (float*)c.take((size_t)n_t * 4);
+  return c.off;
+}
+
+extern "C" size_t dk_mmdit_workspace_bytes(const dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t latent_w, int32_t text_len,
+                                           int32_t n_timesteps) {
+  dk_mmdit tmp = *m;
+  Carver c(nullptr, 0);
+  return mmdit_carve(&tmp, c, batch, latent_h, latent_w, text_len, n_timesteps) + 256;
+}
+
+extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t latent_w, int32_t text_len,
+                                int32_t n_timesteps, void* workspace, size_t workspace_bytes, void* stream) {
+  DK_REQUIRE(m && workspace, "null argument");
+  DK_REQUIRE(batch > 0 && text_len > 0 && n_timesteps > 0, "empty problem");
+  const int p = m->cfg.patch_size;
+  DK_REQUIRE(latent_h % p == 0 && latent_w % p == 0, "latent size must be divisible by the patch size");
+  DK_TRY(mmdit_resolve(m));
+  DK_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  Carver c(workspace, workspace_bytes);
+  const size_t need_bytes = mmdit_carve(m, c, batch, latent_h, latent_w, text_len, n_timesteps);
+  DK_REQUIRE(need_bytes <= workspace_bytes, "workspace too small");
+  m->B = batch; m->Hl = latent_h; m->Wl = latent_w; m->S_t = text_len;
+  m->S_i = (latent_h / p) * (latent_w / p); m->S = m->S_t + m->S_i; m->n_t = n_timesteps;
+  hipStream_t st = S_(stream);
+  if (m->cfg.use_rope)
+    DK_TRY(dk_launch_rope_table(m->rope, m->S_t, latent_h / p, latent_w / p, m->cfg.rope_axes_dim, m->cfg.n_rope_axes,
+                                (float)m->cfg.rope_theta, st));
+  if (m->cfg.use_pos_embed) {
+    // centre crop of the learned table (mmdit.py:334-349): rows y0..y0+gh, cols x0..x0+gw
+    const int mh = m->cfg.max_latent_resolution, gh = latent_h / p, gw = latent_w / p;
+    DK_REQUIRE(gh <= mh && gw <= mh, "latent larger than the positional table");
+    const int y0 = (mh - gh) / 2, x0 = (mh - gw) / 2;
+    DK_CHECK_HIP(hipMemcpy2DAsync(m->POS, (size_t)gw * m->h() * 2, m->pos_w + ((size_t)y0 * mh + x0) * m->h(),
+                                  (size_t)mh * m->h() * 2, (size_t)gw * m->h() * 2, gh, hipMemcpyDeviceToDevice, st));
+  }
+  m->prepared = true;
+  m->mod_ready = false;
+  return 0;
+}
+
+extern "C" int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled, const float* timesteps_host, int32_t n,
+                                                void* stream) {
+  DK_REQUIRE(m && m->prepared, "dk_mmdit_prepare must be called first");
+  DK_REQUIRE(n > 0 && n <= m->n_t, "more timesteps than the workspace was prepared for");
+  hipStream_t st = S_(stream);
+  const int h = m->h(), B = m->B, P = m->cfg.pooled_text_embed_dim, Fq = m->cfg.frequency_embed_dim;
+  DK_CHECK_HIP(hipMemcpyAsync(m->tdev, timesteps_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DK_TRY(dk_launch_timestep_embedding(m->tdev, n, 1, Fq, (float)m->cfg.max_period, m->cfg.embed_dtype, m->temb, st));
+  // t_embedder / y_embedder: Linear -> SiLU -> Linear (mmdit.py:352-392)
+  DK_TRY(linear_plain(m->temb, m->t0_w, m->t0_b, m->t1, n, h, Fq, DK_EPI_BIAS_SILU, st));
+  DK_TRY(linear_plain(m->t1, m->t2_w, m->t2_b, m->tvec, n, h, h, DK_EPI_BIAS, st));
+  DK_TRY(linear_plain((const bf16_t*)pooled, m->y0_w, m->y0_b, m->y1, B, h, P, DK_EPI_BIAS_SILU, st));
+  DK_TRY(linear_plain(m->y1, m->y2_w, m->y2_b, m->yvec, B, h, h, DK_EPI_BIAS, st));
+  // vec[step*B + b] = silu(y[b] + t[step]); adaLN_modulation = SiLU -> Linear (mmdit.py:94-96,430-435)
+  DK_TRY(dk_launch_add(m->yvec, m->tvec, n, m->vec, n * B, h, st));
+  DK_TRY(dk_launch_silu(m->vec, m->vec, (long)n * B * h, st));
+  DK_TRY(linear_plain(m->vec, m->adaln_w, m->adaln_b, m->MOD, n * B, m->mod_rows() * h, h, DK_EPI_BIAS, st));
+  m->mod_ready = true;
+  return 0;
+}
+
+// one TransformerBlock.pre_sdpa (mmdit.py:440-519) on a row range of the joint stream
+static int pre_sdpa(dk_mmdit* m, const StreamW& w, int row_off, int S_s, const bf16_t* mod, int mod_stride, hipStream_t st) {
+  const int h = m->h(), B = m->B, S = m->S, M = B * S_s;
+  DK_TRY(dk_launch_ln_modulate(m->X + (size_t)row_off * h, h, m->XN, h, M, h, mod, mod + h, mod_stride, S_s, S_s, S,
+                               m->cfg.layer_norm_eps, st));
+  DK_TRY(linear_call(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV + (size_t)row_off * 3 * h, 3 * h, S_s, S, M, 3 * h, h,
+                     DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
+  DK_TRY(dk_launch_qk_norm_rope(m->QKV + (size_t)row_off * 3 * h, 3 * h, 0, h, M, m->cfg.num_heads, m->D(), w.qn, w.kn, 1e-6f,
+                                m->cfg.use_rope ? m->rope : nullptr, S_s, S, row_off, m->S, st));
+  return 0;
+}
+
+// sequential TransformerBlock.post_sdpa (mmdit.py:537-548) on a row range
+static int post_sdpa_seq(dk_mmdit* m, const StreamW& w, int row_off, int S_s, const bf16_t* mod, int mod_stride, hipStream_t st) {
+  const int h = m->h(), B = m->B, S = m->S, M = B * S_s, r = m->cfg.mlp_ratio;
+  bf16_t* Xs = m->X + (size_t)row_off * h;
+  // residual += gate_attn * o_proj(attn)
+  DK_TRY(linear_call(m->ATT + (size_t)row_off * h, h, S_s, S, w.o_w, w.o_b, Xs, h, S_s, S, M, h, h, DK_EPI_GATE_RES, mod + 2 * h,
+                     S_s, mod_stride, Xs, h, S_s, S, st));
+  // residual += gate_mlp * fc2(gelu(fc1(LN-mod(residual))))
+  DK_TRY(dk_launch_ln_modulate(Xs, h, m->XN, h, M, h, mod + 3 * h, mod + 4 * h, mod_stride, S_s, S_s, S, m->cfg.layer_norm_eps, st));
+  DK_TRY(linear_call(m->XN, h, M, 0, w.fc1_w, w.fc1_b, m->HID, r * h, M, 0, M, r * h, h, DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr,
+                     0, 0, 0, st));
+  DK_TRY(linear_call(m->HID, r * h, M, 0, w.fc2_w, w.fc2_b, Xs, h, S_s, S, M, h, r * h, DK_EPI_GATE_RES, mod + 5 * h, S_s,
+                     mod_stride, Xs, h, S_s, S, st));
+  return 0;
+}
+
+extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index, void* tokens_out,
+                                void* stream) {
+  DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
+  DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
+  hipStream_t st = S_(stream);
+  const dk_mmdit_config& c = m->cfg;
+  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F(), r = c.mlp_ratio;
+  const int R = m->mod_rows();
+  const int mod_stride = R * h;  // per batch row
+  const bf16_t* mod_step = m->MOD + (size_t)step_index * B * R * h;
+  const float scale = 1.0f / sqrtf((float)m->D());
+
+  // context_embedder (mmdit.py:195): text rows of the joint stream
+  DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, B * S_t, 0, m->ctx_w, m->ctx_b, m->X, h, S_t, S, B * S_t, h,
+                     c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
+  // x_embedder (+ learned positional embedding) (mmdit.py:197-206): image rows
+  DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
+                     c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
+
+  // MultiModalTransformerBlock x depth_multimodal (mmdit.py:568-675)
+  for (int i = 0; i < c.depth_multimodal; ++i) {
+    const bf16_t* mod_img = mod_step + (size_t)m->mod_offset(0, i) * h;
+    const bf16_t* mod_txt = mod_step + (size_t)m->mod_offset(1, i) * h;
+    DK_TRY(pre_sdpa(m, m->dimg[i], S_t, S_i, mod_img, mod_stride, st));
+    DK_TRY(pre_sdpa(m, m->dtxt[i], 0, S_t, mod_txt, mod_stride, st));
+    AttnParams ap;
+    ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
+    ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
+    DK_TRY(dk_launch_attention(ap, st));
+    DK_TRY(post_sdpa_seq(m, m->dimg[i], S_t, S_i, mod_img, mod_stride, st));
+    if (!m->txt_skipped(i)) DK_TRY(post_sdpa_seq(m, m->dtxt[i], 0, S_t, mod_txt, mod_stride, st));
+  }
+
+  // UnifiedTransformerBlock x depth_unified (mmdit.py:693-751), parallel attention + MLP
+  for (int i = 0; i < c.depth_unified; ++i) {
+    const StreamW& w = m->single[i];
+    const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
+    const int M = B * S, ldcat = (1 + r) * h;
+    DK_TRY(dk_launch_ln_modulate(m->X, h, m->XN, h, M, h, mod, mod + h, mod_stride, S, M, 0, c.layer_norm_eps, st));
+    DK_TRY(linear_call(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0,
+                       0, st));
+    DK_TRY(linear_call(m->XN, h, M, 0, w.fc1_w, w.fc1_b, m->CAT + h, ldcat, M, 0, M, r * h, h, DK_EPI_BIAS_GELU, nullptr, 0, 0,
+                       nullptr, 0, 0, 0, st));
+    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
+                                  S, S, 0, S, st));
+    AttnParams ap;
+    ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->CAT;
+    ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = ldcat; ap.scale = scale;
+    DK_TRY(dk_launch_attention(ap, st));
+    // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
+    DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, ldcat, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
+                       m->X, h, M, 0, st));
+  }
+
+  // FinalLayer (mmdit.py:767-796) on the image rows
+  const bf16_t* mod_fin = mod_step + (size_t)m->mod_offset(3, 0) * h;
+  DK_TRY(dk_launch_ln_modulate(m->X + (size_t)S_t * h, h, m->XN, h, B * S_i, h, mod_fin, mod_fin + h, mod_stride, S_i, S_i, S,
+                               c.layer_norm_eps, st));
+  DK_TRY(linear_plain(m->XN, m->final_w, m->final_b, (bf16_t*)tokens_out, B * S_i, F, h, DK_EPI_BIAS, st));
+  return 0;
+}
+
+extern "C" const void* dk_mmdit_debug_buffer(const dk_mmdit* m, int32_t which) {
+  if (!m || !m->prepared) return nullptr;
+  return which == 0 ? (const void*)m->X : which == 1 ? (const void*)m->MOD : nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAE decoder engine (vae.py:336-401)
+// ---------------------------------------------------------------------------------------------
+struct dk_vae {
+  dk_vae_config cfg;
+  std::unordered_map<std::string, const void*> named;
+  // workspace views
+  bf16_t *bufA, *bufB, *T1, *Y, *SC, *LAT, *ZERO, *Qb, *Kb, *Vb, *Vt, *SCORES;
+  float* gn;
+};
+
+extern "C" int dk_vae_create(const dk_vae_config* cfg, dk_vae** out) {
+  DK_REQUIRE(cfg && out, "null argument");
+  DK_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 4, "1..4 resolution levels");
+  for (int i = 0; i < cfg->n_blocks; ++i)
+    DK_REQUIRE(cfg->block_out_channels[i] % 64 == 0, "VAE channel counts must be multiples of 64");
+  DK_REQUIRE(cfg->in_channels <= 64 && cfg->out_channels <= 4, "latent channels <= 64, image channels <= 4");
+  dk_vae* v = new dk_vae();
+  v->cfg = *cfg;
+  *out = v;
+  return 0;
+}
+extern "C" void dk_vae_destroy(dk_vae* v) { delete v; }
+extern "C" int dk_vae_bind(dk_vae* v, const char* name, const void* dev_ptr) {
+  DK_REQUIRE(v && name && dev_ptr, "null argument");
+  v->named[name] = dev_ptr;
+  return 0;
+}
+
+static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
+  const dk_vae_config& cf = v->cfg;
+  // largest activation: walk the decoder (vae.py:386-401) and take max(B * H * W * C)
+  size_t maxel = 0;
+  {
+    size_t H = h, W = w;
+    int Cprev = cf.block_out_channels[cf.n_blocks - 1];
+    maxel = (size_t)B * H * W * Cprev;
+    for (int j = cf.n_blocks - 1; j >= 0; --j) {
+      const int Cout = cf.block_out_channels[j];
+      const size_t e = (size_t)B * H * W * (size_t)(Cprev > Cout ? Cprev : Cout);
+      if (e > maxel) maxel = e;
+      if (j > 0) {
+        H *= 2;
+        W *= 2;
+        if ((size_t)B * H * W * Cout > maxel) maxel = (size_t)B * H * W * Cout;
+      }
+      Cprev = Cout;
+    }
+  }
+  const size_t act = maxel * 2;
+  v->bufA = (bf16_t*)c.take(act);
+  v->bufB = (bf16_t*)c.take(act);
+  v->T1 = (bf16_t*)c.take(act);
+  v->Y = (bf16_t*)c.take(act);
+  v->SC = (bf16_t*)c.take(act);
+  v->LAT = (bf16_t*)c.take((size_t)B * h * w * 64 * 2);
+  v->ZERO = (bf16_t*)c.take(256);
+  const int Cm = cf.block_out_channels[cf.n_blocks - 1];
+  const size_t tok = (size_t)h * w;
+  v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Vt = (bf16_t*)c.take(tok * Cm * 2);
+  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 8) * 2);
+  v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  return c.off;
+}
+extern "C" size_t dk_vae_workspace_bytes(const dk_vae* v, int32_t batch, int32_t latent_h, int32_t latent_w) {
+  dk_vae tmp = *v;
+  Carver c(nullptr, 0);
+  return vae_carve(&tmp, c, batch, latent_h, latent_w) + 256;
+}
+
+struct VaeRun {
+  dk_vae* v;
+  hipStream_t st;
+  int B;
+  int rc = 0;
+  const bf16_t* W(const std::string& name) {
+    const bf16_t* p = nullptr;
+    if (rc == 0) rc = need(v->named, name, &p);
+    return p;
+  }
+  bool has(const std::string& name) const { return v->named.count(name) != 0; }
+  int gn(const bf16_t* x, bf16_t* y, long HW, int C, const std::string& name, int silu) {
+    const bf16_t *g = W(name + ".weight"), *b = W(name + ".bias");
+    if (rc) return rc;
+    return dk_groupnorm_bf16(x, y, B, HW, C, v->cfg.resnet_groups, g, b, v->cfg.group_norm_eps, silu, v->gn, st);
+  }
+  int conv(const bf16_t* x, bf16_t* y, int H, int Wd, int C, int O, const std::string& name, int ups, const bf16_t* res, int ldy) {
+    dk_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.w = W(name + ".weight"); d.bias = W(name + ".bias"); d.y = y; d.res = res; d.zeros = v->ZERO;
+    if (rc) return rc;
+    d.B = B; d.H = H; d.W = Wd; d.C = C; d.O = O; d.ldy = ldy; d.ldr = O; d.upsample = ups;
+    d.epilogue = res ? DK_EPI_RES : DK_EPI_BIAS;
+    return dk_conv3x3_bf16(&d, st);
+  }
+  // ResnetBlock2D (vae.py:60-101): x [B,H,W,Cin] -> out [B,H,W,Cout]
+  int resnet(const bf16_t* x, bf16_t* out, int H, int Wd, int Cin, int Cout, const std::string& p) {
+    const long HW = (long)H * Wd;
+    DK_TRY(gn(x, v->T1, HW, Cin, p + ".norm1", 1));
+    DK_TRY(conv(v->T1, v->Y, H, Wd, Cin, Cout, p + ".conv1", 0, nullptr, Cout));
+    DK_TRY(gn(v->Y, v->T1, HW, Cout, p + ".norm2", 1));
+    const bf16_t* res = x;
+    if (has(p + ".conv_shortcut.weight")) {
+      const bf16_t *sw = W(p + ".conv_shortcut.weight"), *sb = W(p + ".conv_shortcut.bias");
+      if (rc) return rc;
+      DK_TRY(linear_plain(x, sw, sb, v->SC, (int)(B * HW), Cout, Cin, DK_EPI_BIAS, st));
+      res = v->SC;
+    } else {
+      DK_REQUIRE(Cin == Cout, "resnet without shortcut must keep the channel count");
+    }
+    return conv(v->T1, out, H, Wd, Cout, Cout, p + ".conv2", 0, res, Cout);
+  }
+  // single-head attention (vae.py:28-57)
+  int attention(const bf16_t* x, bf16_t* out, int H, int Wd, int C, const std::string& p) {
+    const long HW = (long)H * Wd;
+    const int T = (int)HW;
+    DK_REQUIRE(T % 8 == 0 && T <= 16384, "VAE attention supports up to 16384 tokens (multiple of 8)");
+    DK_TRY(gn(x, v->T1, HW, C, p + ".group_norm", 0));
+    const bf16_t *qw = W(p + ".query_proj.weight"), *qb = W(p + ".query_proj.bias");
+    const bf16_t *kw = W(p + ".key_proj.weight"), *kb = W(p + ".key_proj.bias");
+    const bf16_t *vw = W(p + ".value_proj.weight"), *vb = W(p + ".value_proj.bias");
+    const bf16_t *ow = W(p + ".out_proj.weight"), *ob = W(p + ".out_proj.bias");
+    if (rc) return rc;
+    DK_TRY(linear_plain(v->T1, qw, qb, v->Qb, B * T, C, C, DK_EPI_BIAS, st));
+    DK_TRY(linear_plain(v->T1, kw, kb, v->Kb, B * T, C, C, DK_EPI_BIAS, st));
+    DK_TRY(linear_plain(v->T1, vw, vb, v->Vb, B * T, C, C, DK_EPI_BIAS, st));
+    const float scale = 1.0f / sqrtf((float)C);
+    for (int b = 0; b < B; ++b) {
+      GemmParams g;
+      memset(&g, 0, sizeof(g));
+      g.A = v->Qb + (size_t)b * T * C; g.W = v->Kb + (size_t)b * T * C; g.C = v->SCORES;
+      g.M = T; g.N = T; g.K = C; g.lda = C; g.ldc = T;
+      g.a_seg_len = g.c_seg_len = g.r_seg_len = g.gate_seg_len = T;
+      g.alpha = scale; g.epi = DK_EPI_BIAS;
+      DK_TRY(dk_launch_gemm(g, st));
+      DK_TRY(dk_launch_softmax_rows(v->SCORES, T, T, T, st));
+      DK_TRY(dk_launch_transpose(v->Vb + (size_t)b * T * C, v->Vt, T, C, st));
+      // attn @ V: A = probs [T,T], W = V^T [C,T]; result into Y rows of this batch
+      DK_REQUIRE(T % 64 == 0, "VAE attention token count must be a multiple of 64");
+      DK_TRY(linear_plain(v->SCORES, v->Vt, nullptr, v->Y + (size_t)b * T * C, T, C, T, DK_EPI_BIAS, st));
+    }
+    // out_proj + residual
+    return linear_call(v->Y, C, B * T, 0, ow, ob, out, C, B * T, 0, B * T, C, C, DK_EPI_RES, nullptr, 0, 0, x, C, B * T, 0, st);
+  }
+};
+
+extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int32_t latent_h, int32_t latent_w, float* image_f32,
+                             uint8_t* image_u8, void* raw_bf16, void* workspace, size_t workspace_bytes, void* stream) {
+  DK_REQUIRE(v && latent && workspace, "null argument");
+  DK_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  Carver c(workspace, workspace_bytes);
+  const size_t need_bytes = vae_carve(v, c, batch, latent_h, latent_w);
+  DK_REQUIRE(need_bytes <= workspace_bytes, "workspace too small");
+  const dk_vae_config& cf = v->cfg;
+  VaeRun R{v, S_(stream), batch};
+  hipStream_t st = R.st;
+  DK_CHECK_HIP(hipMemsetAsync(v->ZERO, 0, 256, st));
+  int H = latent_h, W = latent_w;
+  const int Cm = cf.block_out_channels[cf.n_blocks - 1];
+  DK_TRY(dk_launch_pad_channels(latent, v->LAT, (long)batch * H * W, cf.in_channels, 64, st));
+  bf16_t *cur = v->bufA, *nxt = v->bufB;
+  DK_TRY(R.conv(v->LAT, cur, H, W, 64, Cm, "conv_in", 0, nullptr, Cm));
+  DK_TRY(R.resnet(cur, nxt, H, W, Cm, Cm, "mid_blocks.0")); std::swap(cur, nxt);
+  DK_TRY(R.attention(cur, nxt, H, W, Cm, "mid_blocks.1")); std::swap(cur, nxt);
+  DK_TRY(R.resnet(cur, nxt, H, W, Cm, Cm, "mid_blocks.2")); std::swap(cur, nxt);
+  int C = Cm;
+  // up_blocks list index n-1 runs first (vae.py:379,393); index 0 has no upsample conv
+  for (int j = cf.n_blocks - 1; j >= 0; --j) {
+    const int Cout = cf.block_out_channels[j];
+    for (int r = 0; r < cf.layers_per_block; ++r) {
+      const std::string p = "up_blocks." + std::to_string(j) + ".resnets." + std::to_string(r);
+      DK_TRY(R.resnet(cur, nxt, H, W, r == 0 ? C : Cout, Cout, p)); std::swap(cur, nxt);
+    }
+    C = Cout;
+    if (j > 0) {
+      H *= 2; W *= 2;
+      DK_TRY(R.conv(cur, nxt, H, W, C, C, "up_blocks." + std::to_string(j) + ".upsample", 1, nullptr, C)); std::swap(cur, nxt);
+    }
+  }
+  DK_TRY(R.gn(cur, v->T1, (long)H * W, C, "conv_norm_out", 1));
+  bf16_t* raw = raw_bf16 ? (bf16_t*)raw_bf16 : v->Y;
+  DK_TRY(R.conv(v->T1, raw, H, W, C, cf.out_channels, "conv_out", 0, nullptr, 4));
+  DK_TRY(dk_launch_image_post(raw, 4, image_f32, image_u8, (long)batch * H * W, st));
+  return R.rc;
+}

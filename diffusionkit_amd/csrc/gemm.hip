@@ -1,0 +1,252 @@
+// bf16 MFMA GEMM for gfx950: C = epi(alpha * A . W^T + bias), fp32 accumulate.
+//
+// Replaces every nn.Linear / nn.Conv2d call site of the reference hot path
+// (python/src/diffusionkit/mlx/mmdit.py:56,285,358-360,373-375,432,771,777,821-832;
+//  python/src/diffusionkit/mlx/vae.py:36-39,73,79,84,134,349,384).
+//
+// Tile: 128(M) x 128(N) x 64(K) per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
+// v_mfma_f32_32x32x16_bf16).  Both operands are K-major, staged HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip) into a double-buffered 2 x 32 KiB image.
+// The LDS image is lane-linear (a DMA constraint); bank conflicts on the ds_read_b128
+// fragment reads are removed by XOR-ing the 16-byte chunk index with (row>>1)&7 on the
+// *source* address and again on the read (same involution both sides).
+// The MFMA is issued with operands swapped (W-fragment as A, X-fragment as B) so each lane
+// ends up owning one output row and 4-element runs of consecutive columns: the epilogue
+// (bias, GELU, gate*x+residual) then works on 8-byte vectors.
+// AMODE=1 turns the A loader into an im2col gather for 3x3/pad-1 convolution over NHWC
+// (optionally reading a nearest-x2-upsampled view), padding taps read a zero page.
+#include "dk_kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define A_TILE_BYTES (BM * BK * 2)
+#define B_TILE_BYTES (BN * BK * 2)
+#define STAGE_BYTES (A_TILE_BYTES + B_TILE_BYTES)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ int lds_row_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <int AMODE>
+__global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // ---- workgroup -> tile: XCD-contiguous chunks, then 8-row groups (A/W panels shared in L2) ----
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int t;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int GROUP = 8;
+  const int tpg = GROUP * nbn;
+  const int g = t / tpg;
+  const int first_m = g * GROUP;
+  const int gsz = min(nbm - first_m, GROUP);
+  const int tm = first_m + (t % tpg) % gsz;
+  const int tn = (t % tpg) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane source pointers for the DMA loads (4 A + 4 W row-instructions per wave) ----
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+  int cy[4], cx[4];       // conv: output pixel coordinates of this lane's rows
+  long cimg[4];           // conv: image base (elements)
+  const int srow = lane >> 3;  // row within an 8-row instruction
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + srow;  // tile-local row
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    int n = min(n0 + r, p.N - 1);
+    w_src[i] = p.W + (size_t)n * p.K + chunk * 8;
+    int m = min(m0 + r, p.M - 1);
+    if (AMODE == 0) {
+      const int phys = (m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len);
+      a_src[i] = p.A + (size_t)phys * p.lda + chunk * 8;
+    } else {
+      const int hw = p.cH * p.cW;
+      const int b = m / hw, rem = m - b * hw;
+      cy[i] = rem / p.cW;
+      cx[i] = rem - cy[i] * p.cW;
+      const int Hs = p.ups ? (p.cH >> 1) : p.cH, Ws = p.ups ? (p.cW >> 1) : p.cW;
+      cimg[i] = (long)b * Hs * Ws * p.cC + chunk * 8;
+      a_src[i] = p.zeros + chunk * 8;
+    }
+  }
+
+  const int nk = p.K / BK;
+  const int cpt = (AMODE == 1) ? (p.cC / BK) : 1;  // K-tiles per conv tap
+
+  auto issue = [&](int kt, int buf) {
+    char* abase = smem + buf * STAGE_BYTES + (wave * 32) * 128;
+    char* bbase = abase + A_TILE_BYTES;
+    if (AMODE == 1) {
+      const int tap = kt / cpt, cb = (kt - tap * cpt) * BK;
+      const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+      const int Ws = p.ups ? (p.cW >> 1) : p.cW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = cy[i] + ky, ix = cx[i] + kx;
+        const bool ok = (iy >= 0) && (iy < p.cH) && (ix >= 0) && (ix < p.cW);
+        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+        const bf16_t* src = ok ? (p.A + cimg[i] + ((long)sy * Ws + sx) * p.cC + cb) : a_src[i];
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(abase + i * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(abase + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + kt * BK), (lds_ptr_t)(bbase + i * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const char* As = smem + buf * STAGE_BYTES;
+    const char* Bs = As + A_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + hi;
+      bf16x8 wf[2], xf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i] = *(const bf16x8*)(Bs + lds_row_off(wn * 64 + i * 32 + l31, c));
+        xf[i] = *(const bf16x8*)(As + lds_row_off(wm * 64 + i * 32 + l31, c));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row m (per mi) and columns nb + {0..3} per (ni, g) ----
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= p.M) continue;
+    const size_t crow = (size_t)((m / p.c_seg_len) * p.c_seg_stride + (m % p.c_seg_len)) * p.ldc;
+    size_t rrow = 0;
+    const bf16_t* gate = nullptr;
+    if (p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES)
+      rrow = (size_t)((m / p.r_seg_len) * p.r_seg_stride + (m % p.r_seg_len)) * p.ldr;
+    if (p.epi == DK_EPI_GATE_RES) gate = p.gate + (size_t)(m / p.gate_seg_len) * p.gate_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nb = n0 + wn * 64 + ni * 32 + 8 * g4 + 4 * hi;
+        if (nb >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g4 + e] * p.alpha;
+        const bool full = (nb + 3 < p.N);
+        if (full) {
+          if (p.bias) {
+            const uint2 bb = *(const uint2*)(p.bias + nb);
+            float b0, b1, b2, b3;
+            unpack2bf(bb.x, b0, b1);
+            unpack2bf(bb.y, b2, b3);
+            v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]);
+          if (p.epi == DK_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+          } else if (p.epi == DK_EPI_BIAS_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES) {
+            const uint2 rr = *(const uint2*)(p.res + rrow + nb);
+            float r0, r1, r2, r3;
+            unpack2bf(rr.x, r0, r1);
+            unpack2bf(rr.y, r2, r3);
+            if (p.epi == DK_EPI_GATE_RES) {
+              const uint2 gg = *(const uint2*)(gate + nb);
+              float g0, g1, g2, g3;
+              unpack2bf(gg.x, g0, g1);
+              unpack2bf(gg.y, g2, g3);
+              v[0] = r0 + round_bf16(g0 * v[0]);
+              v[1] = r1 + round_bf16(g1 * v[1]);
+              v[2] = r2 + round_bf16(g2 * v[2]);
+              v[3] = r3 + round_bf16(g3 * v[3]);
+            } else {
+              v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+            }
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *(uint2*)(p.C + crow + nb) = o;
+        } else {
+          for (int e = 0; e < 4 && nb + e < p.N; ++e) {
+            float x = v[e];
+            if (p.bias) x += bf2f(p.bias[nb + e]);
+            x = round_bf16(x);
+            if (p.epi == DK_EPI_BIAS_GELU) x = gelu_erf_f(x);
+            else if (p.epi == DK_EPI_BIAS_SILU) x = silu_f(x);
+            else if (p.epi == DK_EPI_GATE_RES) x = bf2f(p.res[rrow + nb + e]) + round_bf16(bf2f(gate[nb + e]) * x);
+            else if (p.epi == DK_EPI_RES) x += bf2f(p.res[rrow + nb + e]);
+            p.C[crow + nb + e] = f2bf(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+int dk_launch_gemm(const GemmParams& p, hipStream_t stream) {
+  DK_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
+  DK_REQUIRE(p.K % BK == 0, "K must be a multiple of 64");
+  DK_REQUIRE(p.ldc % 4 == 0, "ldc must be a multiple of 4 elements");
+  DK_REQUIRE(p.conv || (p.lda % 8 == 0), "lda must be a multiple of 8 elements");
+  if (p.conv) {
+    DK_REQUIRE(p.cC % BK == 0 && p.K == 9 * p.cC, "conv: C must be a multiple of 64 and K = 9*C");
+    DK_REQUIRE(p.M == p.cB * p.cH * p.cW, "conv: M must equal B*H*W");
+    DK_REQUIRE(p.zeros != nullptr, "conv: zero page missing");
+  }
+  if (p.epi == DK_EPI_GATE_RES) DK_REQUIRE(p.gate && p.res, "gate/res missing");
+  if (p.epi == DK_EPI_RES) DK_REQUIRE(p.res, "res missing");
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+    attr_set = true;
+  }
+  dim3 grid(nbm * nbn), block(256);
+  if (p.conv)
+    hipLaunchKernelGGL(dk_gemm_bf16_kernel<1>, grid, block, 2 * STAGE_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL(dk_gemm_bf16_kernel<0>, grid, block, 2 * STAGE_BYTES, stream, p);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,237 @@
+// HBM-bound kernels of the latent-decode VAE (NHWC bf16): GroupNorm statistics / apply(+SiLU),
+// row softmax for the single-head mid-block attention, 2-D transpose, channel padding and the
+// final clip + uint8 conversion.
+// reference: python/src/diffusionkit/mlx/vae.py:28-57 (Attention), :60-101 (ResnetBlock2D),
+// :381,397-399 (conv_norm_out + silu), python/src/diffusionkit/mlx/__init__.py:581-584,525-526.
+#include "dk_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics (nn.GroupNorm(pytorch_compatible=True): per (batch, group) mean / variance
+// over H*W*(C/G) elements, fp32).  Pass 1: each workgroup reduces a slab of pixels into per-group
+// (sum, sumsq) partials; pass 2 combines the partials in double precision.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __restrict__ x, long HW, int C, int G, float* __restrict__ partial,
+                                                            int nchunk) {
+  __shared__ float gs[2 * 64];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  if (tid < 2 * G) gs[tid] = 0.f;
+  __syncthreads();
+  const int tpp = C / 8;           // threads per pixel
+  const int ppi = 256 / tpp;       // pixels per iteration
+  const int cg = tid % tpp;        // channel chunk of this thread
+  const int pl = tid / tpp;
+  const long per = (HW + nchunk - 1) / nchunk;
+  const long p0 = (long)chunk * per, p1 = min(HW, p0 + per);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (pl < ppi) {
+    const bf16_t* base = x + (size_t)b * HW * C + cg * 8;
+    for (long pix = p0 + pl; pix < p1; pix += ppi) {
+      const u32x4 raw = *(const u32x4*)(base + (size_t)pix * C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a0, a1;
+        unpack2bf(raw[e], a0, a1);
+        s[2 * e] += a0; q[2 * e] += a0 * a0;
+        s[2 * e + 1] += a1; q[2 * e + 1] += a1 * a1;
+      }
+    }
+    const int cpg = C / G;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (cg * 8 + e) / cpg;
+      atomicAdd(&gs[2 * g], s[e]);
+      atomicAdd(&gs[2 * g + 1], q[e]);
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * G) partial[((size_t)b * nchunk + chunk) * 2 * G + tid] = gs[tid];
+}
+__global__ void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
+                                      float* __restrict__ mean_rstd) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= G) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    s += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g];
+    q += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g + 1];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
+  mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, float* mean_rstd,
+                              float eps, hipStream_t stream) {
+  DK_REQUIRE(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "channels must be 8 * 2^k <= 2048");
+  DK_REQUIRE(G <= 64 && C % G == 0, "groups");
+  DK_REQUIRE(nchunk >= 1, "nchunk");
+  hipLaunchKernelGGL(dk_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, HW, C, G, partial, nchunk);
+  DK_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B), dim3(64), 0, stream, partial, nchunk, G,
+                     (double)HW * (double)(C / G), eps, mean_rstd);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// y = [silu]( bf16( (x - mean) * rstd * gamma + beta ) )
+__global__ __launch_bounds__(256) void dk_gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long HW, int C, int G,
+                                                          const float* __restrict__ mean_rstd, const bf16_t* __restrict__ gamma,
+                                                          const bf16_t* __restrict__ beta, int do_silu, long total_chunks) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int cpr = C / 8;
+  const int cg = (int)(i % cpr);
+  const long pix = i / cpr;  // global pixel index over batch
+  const int b = (int)(pix / HW);
+  const int cpg = C / G;
+  const u32x4 raw = *(const u32x4*)(x + (size_t)i * 8);
+  const u32x4 gr = *(const u32x4*)(gamma + cg * 8);
+  const u32x4 br = *(const u32x4*)(beta + cg * 8);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a0, a1, g0, g1, b0, b1;
+    unpack2bf(raw[e], a0, a1);
+    unpack2bf(gr[e], g0, g1);
+    unpack2bf(br[e], b0, b1);
+    const int c0 = cg * 8 + 2 * e;
+    const float* mr0 = mean_rstd + ((size_t)b * G + c0 / cpg) * 2;
+    const float* mr1 = mean_rstd + ((size_t)b * G + (c0 + 1) / cpg) * 2;
+    float y0 = round_bf16((a0 - mr0[0]) * mr0[1] * g0 + b0);
+    float y1 = round_bf16((a1 - mr1[0]) * mr1[1] * g1 + b1);
+    if (do_silu) {
+      y0 = silu_f(y0);
+      y1 = silu_f(y1);
+    }
+    o[e] = pack2bf(y0, y1);
+  }
+  *(u32x4*)(y + (size_t)i * 8) = o;
+}
+int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,
+                              const bf16_t* gamma, const bf16_t* beta, int do_silu, hipStream_t stream) {
+  const long total = (long)B * HW * (C / 8);
+  hipLaunchKernelGGL(dk_gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, HW, C, G, mean_rstd,
+                     gamma, beta, do_silu, total);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-place row softmax on a bf16 matrix (fp32 math), one workgroup per row, row cached in
+// registers (cols <= 16384).  reference: mx.softmax(scores) in vae.py:51.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict__ x, int cols, int ld) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16_t* row = x + (size_t)blockIdx.x * ld;
+  const int nchunks = cols >> 3;
+  float v[8][8];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nchunks) {
+      const u32x4 raw = *(const u32x4*)(row + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unpack2bf(raw[e], v[i][2 * e], v[i][2 * e + 1]);
+        mx = fmaxf(mx, fmaxf(v[i][2 * e], v[i][2 * e + 1]));
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = __expf(v[i][e] - mx);
+        sum += v[i][e];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nchunks) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[i][2 * e] * inv, v[i][2 * e + 1] * inv);
+      *(u32x4*)(row + c * 8) = o;
+    }
+  }
+}
+int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t stream) {
+  DK_REQUIRE(cols % 8 == 0 && cols <= 16384 && ld % 8 == 0, "softmax row length must be a multiple of 8 and <= 16384");
+  hipLaunchKernelGGL(dk_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, cols, ld);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// y[c, r] = x[r, c]
+__global__ void dk_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int R, int Cc) {
+  __shared__ bf16_t tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    if (r < R && c < Cc) tile[j][tx] = x[(size_t)r * Cc + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (r < R && c < Cc) y[(size_t)c * R + r] = tile[tx][j];
+  }
+}
+int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream) {
+  hipLaunchKernelGGL(dk_transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, x, y, R, Cc);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// fp32 [npix, C] -> bf16 [npix, Cpad] with zero channel padding (latents enter the conv_in GEMM)
+__global__ void dk_pad_channels_kernel(const float* x, bf16_t* y, long npix, int C, int Cpad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * Cpad) return;
+  const int c = (int)(i % Cpad);
+  const long pix = i / Cpad;
+  y[i] = c < C ? f2bf(x[pix * C + c]) : (bf16_t)0;
+}
+int dk_launch_pad_channels(const float* x, bf16_t* y, long npix, int C, int Cpad, hipStream_t stream) {
+  const long n = npix * Cpad;
+  hipLaunchKernelGGL(dk_pad_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, npix, C, Cpad);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// decode_latents_to_image tail (mlx/__init__.py:581-584, 525-526) evaluated in the activation
+// dtype like the reference: img = clip(bf16(x/2 + 0.5), 0, 1); u8 = uint8(bf16(img * 255)).
+__global__ void dk_image_post_kernel(const bf16_t* x, int ldx, float* img, unsigned char* u8, long npix) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * 3) return;
+  const int c = (int)(i % 3);
+  const long pix = i / 3;
+  float v = round_bf16(bf2f(x[pix * ldx + c]) * 0.5f + 0.5f);
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  if (img) img[i] = v;
+  if (u8) u8[i] = (unsigned char)round_bf16(v * 255.0f);
+}
+int dk_launch_image_post(const bf16_t* x, int ldx, float* img, unsigned char* u8, long npix, hipStream_t stream) {
+  const long n = npix * 3;
+  hipLaunchKernelGGL(dk_image_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, img, u8, npix);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

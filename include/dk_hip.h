@@ -1,0 +1,216 @@
+/*
+ * dk_hip.h -- C ABI of libdk_hip.so: the MI355X (gfx950) denoising engine behind
+ * DiffusionKit's DiffusionPipeline / FluxPipeline.
+ *
+ * The reference (argmaxinc/DiffusionKit, python/src/diffusionkit/mlx/) has no FFI layer: its
+ * hot path is Python calling MLX ops.  This header *creates* the boundary a maintainer would
+ * bind (ctypes stub in INTEGRATION.md).  Each entry point cites the reference call site it
+ * replaces; paths are relative to python/src/diffusionkit/mlx/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses
+ *     (torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (torch.cuda.current_stream().cuda_stream); 0 = the null stream.
+ *   - the caller owns every buffer, including the workspaces sized by *_workspace_bytes().
+ *   - all activations / weights are bfloat16 (raw uint16 storage) unless a name says f32.
+ *   - every function returns 0 on success, <0 on error; dk_last_error() describes the last
+ *     failure of the calling thread.  Nothing throws across the ABI.
+ *   - no hidden host synchronisation and no internal threads: work is enqueued on `stream`.
+ *   - tensors are token-major / NHWC, exactly the layouts of the reference's MLX arrays.
+ */
+#ifndef DK_HIP_H
+#define DK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DK_ABI_VERSION 1
+
+int dk_abi_version(void);
+const char* dk_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator level (one MLX op call site each).  These are what the parity tests drive.
+ * ---------------------------------------------------------------------------------------- */
+
+/* epilogues of dk_gemm_bf16 / dk_conv3x3_bf16 */
+enum {
+  DK_EPI_BIAS = 0,      /* C = A W^T + b                      nn.Linear, mmdit.py:56,821-832          */
+  DK_EPI_BIAS_GELU = 1, /* C = gelu_erf(A W^T + b)            FFN fc1 + nn.GELU(), mmdit.py:421,835   */
+  DK_EPI_GATE_RES = 2,  /* C = res + gate[b,:] * (A W^T + b)  post_sdpa gating, mmdit.py:533-548      */
+  DK_EPI_RES = 3,       /* C = res + (A W^T + b)              VAE residual adds, vae.py:99,54         */
+  DK_EPI_BIAS_SILU = 4  /* C = silu(A W^T + b)                embedder MLPs, mmdit.py:357-361,372-376 */
+};
+
+typedef struct dk_gemm_desc {
+  const void* A;    /* [M, K] bf16, row stride lda (elements)                       */
+  const void* W;    /* [N, K] bf16 contiguous (nn.Linear weight layout [out, in])   */
+  void* C;          /* [M, N] bf16, row stride ldc                                  */
+  const void* bias; /* [N] bf16 or NULL                                             */
+  const void* gate; /* DK_EPI_GATE_RES: [n_batch, gate_stride] bf16                 */
+  const void* res;  /* DK_EPI_GATE_RES / DK_EPI_RES: residual, row stride ldr       */
+  int32_t M, N, K;
+  int32_t lda, ldc, ldr;
+  /* logical row m -> physical row (m / seg_len) * seg_stride + m % seg_len.  seg_len = M,
+   * seg_stride = 0 addresses a plain matrix; (S_img, S) addresses the image rows of a joint
+   * [B, S, h] buffer whose base pointer was advanced to the first image row. */
+  int32_t a_seg_len, a_seg_stride;
+  int32_t c_seg_len, c_seg_stride;
+  int32_t r_seg_len, r_seg_stride;
+  int32_t gate_seg_len; /* batch index of row m is m / gate_seg_len */
+  int32_t gate_stride;
+  float alpha;          /* scales the accumulator before the bias (1.0 for Linear) */
+  int32_t epilogue;
+} dk_gemm_desc;
+
+/* nn.Linear call sites of the hot path: mmdit.py:56,358-360,373-375,432,771,777,821-832;
+ * vae.py:36-39,84 */
+int dk_gemm_bf16(const dk_gemm_desc* d, void* stream);
+
+typedef struct dk_conv_desc {
+  const void* x;    /* NHWC bf16 [B, H(/2), W(/2), C]; C multiple of 64              */
+  const void* w;    /* [O, 3, 3, C] bf16 (MLX nn.Conv2d weight layout)               */
+  void* y;          /* NHWC bf16 [B, H, W, ldy>=O]                                   */
+  const void* bias; /* [O] or NULL                                                   */
+  const void* res;  /* DK_EPI_RES: NHWC [B, H, W, ldr]                               */
+  const void* zeros;/* >= 128 bytes of zeros on the device (padding taps)            */
+  int32_t B, H, W, C, O; /* H, W are OUTPUT sizes                                     */
+  int32_t ldy, ldr;
+  int32_t upsample; /* 1: conv over the nearest-x2 upsampling of x (vae.py:20-25,146) */
+  int32_t epilogue;
+} dk_conv_desc;
+
+/* nn.Conv2d 3x3 / stride 1 / pad 1 call sites: vae.py:73,79,134,349,384 */
+int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream);
+
+/* mx.fast.scaled_dot_product_attention call sites mmdit.py:562,643,687,736.
+ * q/k/v: row (b*S + s) at ptr + (b*S + s)*ld + head*D; out likewise with ldo.  D in {64,128}. */
+int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                      int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, void* stream);
+
+/* affine_transform + LayerNorm, mmdit.py:958-972, 838-849.
+ * out[m,:] = LN(x[m,:]) * (1 + scale[b,:]) + shift[b,:], b = m / mod_seg_len. */
+int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t M, int32_t h,
+                        const void* shift, const void* scale, int32_t mod_stride, int32_t mod_seg_len,
+                        int32_t x_seg_len, int32_t x_seg_stride, float eps, void* stream);
+
+/* QKNorm (mmdit.py:754-764) + RoPE.apply (mmdit.py:934-942), in place on the q / k column groups
+ * of a token-major QKV buffer.  q_weight/k_weight NULL = no norm; rope_table NULL = no rotation.
+ * rope_table: f32 [S_pos, D/2, 2] (cos, sin); row m uses position pos_off + m % row_seg_len. */
+int dk_qk_norm_rope_bf16(void* qkv, int32_t ld, int32_t q_off, int32_t k_off, int32_t rows, int32_t H,
+                         int32_t D, const void* q_weight, const void* k_weight, float eps,
+                         const float* rope_table, int32_t row_seg_len, int32_t row_seg_stride,
+                         int32_t pos_off, void* stream);
+
+/* RoPE.rope / _get_positions, mmdit.py:865-911: table f32 [S_txt + gh*gw, sum(axes)/2, 2] */
+int dk_rope_table_f32(float* table, int32_t S_txt, int32_t gh, int32_t gw, const int32_t* axes_dim,
+                      int32_t n_axes, float theta, void* stream);
+
+/* TimestepAdapter.timestep_embedding, mmdit.py:379-389 (quirk Q2). embed_dtype: 0 bf16, 1 fp16, 2 fp32 */
+int dk_timestep_embedding_bf16(const float* t_dev, int32_t n, int32_t dim, float max_period,
+                               int32_t embed_dtype, void* out, void* stream);
+
+/* LatentImageAdapter patchify, mmdit.py:292-300 (reshape_order=1) / :285-290 (0):
+ * latent f32 [n_img,Hl,Wl,C] -> tokens bf16 [n_img*dup, S_i, p*p*C] */
+int dk_latent_to_tokens(const float* x, void* tokens, int32_t n_img, int32_t dup, int32_t Hl, int32_t Wl,
+                        int32_t C, int32_t p, int32_t reshape_order, void* stream);
+
+/* One Euler step incl. unpatchify, x0 prediction, CFG and re-patchify:
+ * CFGDenoiser.__call__ (__init__.py:691-719) after the MMDiT call, to_d (:756),
+ * sample_euler body (:778-781), unpack/unpatchify (mmdit.py:304-321, 975-988).
+ * x: f32 [n_img,Hl,Wl,C] updated in place; model_out: bf16 [n_img*(1+cfg_on), S_i, ld_out];
+ * tokens: next step's patchified input. */
+int dk_euler_cfg_step(float* x, const void* model_out, int32_t ld_out, void* tokens, int32_t n_img,
+                      int32_t cfg_on, int32_t Hl, int32_t Wl, int32_t C, int32_t p, int32_t reshape_order,
+                      float sigma, float sigma_next, float cfg_weight, void* stream);
+
+/* LatentFormat.process_in/out, __init__.py:729-733: y = x * a + b (f32) */
+int dk_affine_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
+
+/* nn.GroupNorm(pytorch_compatible=True) [+ nn.silu], vae.py:34,72,78,381,91,96,398.
+ * x, y: NHWC bf16 [B, HW, C]; scratch_f32 needs dk_groupnorm_scratch_floats(B, G) floats. */
+size_t dk_groupnorm_scratch_floats(int32_t B, int32_t G);
+int dk_groupnorm_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* gamma,
+                      const void* beta, float eps, int32_t fuse_silu, float* scratch_f32, void* stream);
+
+/* mx.softmax(scores, axis=-1), vae.py:51: in place over rows of a bf16 matrix */
+int dk_softmax_rows_bf16(void* x, int32_t rows, int32_t cols, int32_t ld, void* stream);
+int dk_transpose_bf16(const void* x, void* y, int32_t R, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model level: MMDiT (mmdit.py:22-266) and VAEDecoder (vae.py:336-401)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dk_mmdit_config {
+  int32_t num_heads, depth_multimodal, depth_unified, hidden_size, mlp_ratio;
+  int32_t vae_latent_dim, patch_size, patchify_via_reshape;
+  int32_t use_qk_norm, use_rope, rope_axes_dim[4], n_rope_axes, rope_theta;
+  int32_t use_pos_embed, max_latent_resolution;
+  int32_t pooled_text_embed_dim, token_level_text_embed_dim, frequency_embed_dim, max_period;
+  int32_t embed_dtype; /* dtype the timestep embedding is evaluated in: 0 bf16, 1 fp16, 2 fp32 */
+  float layer_norm_eps;
+} dk_mmdit_config;
+
+typedef struct dk_mmdit dk_mmdit;
+
+int dk_mmdit_create(const dk_mmdit_config* cfg, dk_mmdit** out);
+void dk_mmdit_destroy(dk_mmdit* m);
+
+/* Weight binding by name (model.load_weights / model.update, model_io.py:743,783).  Names follow
+ * the reference module tree with the fused tensors of diffusionkit_amd/weights.py:
+ *   <block>.attn.qkv.{weight,bias}, <single block>.linear2.{weight,bias}, adaLN.{weight,bias}.
+ * The pointer must stay valid for the lifetime of the handle. */
+int dk_mmdit_bind(dk_mmdit* m, const char* name, const void* dev_ptr);
+/* number of hidden_size-wide rows of the packed adaLN output, and the row offset of one module
+ * (kind 0 image stream of double block i, 1 text stream, 2 single block i, 3 final layer) */
+int dk_mmdit_mod_rows(const dk_mmdit* m);
+int dk_mmdit_mod_offset(const dk_mmdit* m, int32_t kind, int32_t index);
+
+size_t dk_mmdit_workspace_bytes(const dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t latent_w,
+                                int32_t text_len, int32_t n_timesteps);
+/* fixes the problem shape, carves the workspace, builds RoPE table / cropped pos-emb */
+int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t latent_w, int32_t text_len,
+                     int32_t n_timesteps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* MMDiT.cache_modulation_params(pooled_text_embeddings, timesteps), mmdit.py:77-180.
+ * pooled: bf16 [batch, pooled_dim] on the device; timesteps: n host floats (already rounded to
+ * the activation dtype by the caller, quirk Q1). */
+int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled, const float* timesteps_host,
+                                     int32_t n, void* stream);
+
+/* MMDiT.__call__ (mmdit.py:188-266) between patchify and unpatchify, for cached timestep
+ * `step_index` (quirk Q11: index instead of float key).
+ * tokens_in: bf16 [batch, S_i, p*p*C]; text: bf16 [batch, S_t, text_dim];
+ * tokens_out: bf16 [batch, S_i, p*p*C] (FinalLayer output). */
+int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index,
+                     void* tokens_out, void* stream);
+/* read-only view of an internal buffer for parity taps: 0 = joint residual stream [B,S,h],
+ * 1 = modulation table [n*B, rows*h] */
+const void* dk_mmdit_debug_buffer(const dk_mmdit* m, int32_t which);
+
+typedef struct dk_vae_config {
+  int32_t in_channels, out_channels, block_out_channels[4], n_blocks, layers_per_block, resnet_groups;
+  float group_norm_eps;
+} dk_vae_config;
+typedef struct dk_vae dk_vae;
+int dk_vae_create(const dk_vae_config* cfg, dk_vae** out);
+void dk_vae_destroy(dk_vae* v);
+/* names = reference module tree (vae.py / model_io.py:411-486), conv weights flattened to
+ * [O, 9*I]; conv_in.weight zero-padded to I = 64 */
+int dk_vae_bind(dk_vae* v, const char* name, const void* dev_ptr);
+size_t dk_vae_workspace_bytes(const dk_vae* v, int32_t batch, int32_t latent_h, int32_t latent_w);
+/* VAEDecoder.__call__ (vae.py:386-401) + decode_latents_to_image (__init__.py:581-584) +
+ * uint8 conversion (__init__.py:525-526).  latent: f32 [B,h,w,16];
+ * image_f32: [B,8h,8w,3] in [0,1] or NULL; image_u8: [B,8h,8w,3] or NULL;
+ * raw_bf16: decoder output before the clip, [B,8h,8w,4] (3 used) or NULL. */
+int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int32_t latent_h, int32_t latent_w,
+                  float* image_f32, uint8_t* image_u8, void* raw_bf16, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DK_HIP_H */
