@@ -1,0 +1,135 @@
+"""ctypes binding of libdk_hip.so (include/dk_hip.h).
+
+The product path has no CPU fallback: if the HIP extension is missing or an entry point
+fails, a ``DkHipError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdk_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dk_hip.h")
+
+
+class DkHipError(RuntimeError):
+    pass
+
+
+class dk_gemm_desc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("gate", C.c_void_p), ("res", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+        ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int32),
+        ("c_seg_len", C.c_int32), ("c_seg_stride", C.c_int32),
+        ("r_seg_len", C.c_int32), ("r_seg_stride", C.c_int32),
+        ("gate_seg_len", C.c_int32), ("gate_stride", C.c_int32),
+        ("alpha", C.c_float), ("epilogue", C.c_int32),
+    ]
+
+
+class dk_conv_desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p),
+        ("res", C.c_void_p), ("zeros", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("O", C.c_int32),
+        ("ldy", C.c_int32), ("ldr", C.c_int32), ("upsample", C.c_int32), ("epilogue", C.c_int32),
+    ]
+
+
+class dk_mmdit_config(C.Structure):
+    _fields_ = [
+        ("num_heads", C.c_int32), ("depth_multimodal", C.c_int32), ("depth_unified", C.c_int32),
+        ("hidden_size", C.c_int32), ("mlp_ratio", C.c_int32),
+        ("vae_latent_dim", C.c_int32), ("patch_size", C.c_int32), ("patchify_via_reshape", C.c_int32),
+        ("use_qk_norm", C.c_int32), ("use_rope", C.c_int32), ("rope_axes_dim", C.c_int32 * 4),
+        ("n_rope_axes", C.c_int32), ("rope_theta", C.c_int32),
+        ("use_pos_embed", C.c_int32), ("max_latent_resolution", C.c_int32),
+        ("pooled_text_embed_dim", C.c_int32), ("token_level_text_embed_dim", C.c_int32),
+        ("frequency_embed_dim", C.c_int32), ("max_period", C.c_int32),
+        ("embed_dtype", C.c_int32), ("layer_norm_eps", C.c_float),
+    ]
+
+
+class dk_vae_config(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("block_out_channels", C.c_int32 * 4),
+        ("n_blocks", C.c_int32), ("layers_per_block", C.c_int32), ("resnet_groups", C.c_int32),
+        ("group_norm_eps", C.c_float),
+    ]
+
+
+DK_EPI_BIAS, DK_EPI_BIAS_GELU, DK_EPI_GATE_RES, DK_EPI_RES, DK_EPI_BIAS_SILU = range(5)
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/dk_hip.h declares
+SIGNATURES = {
+    "dk_abi_version": (_i32, []),
+    "dk_last_error": (C.c_char_p, []),
+    "dk_gemm_bf16": (_i32, [C.POINTER(dk_gemm_desc), _vp]),
+    "dk_conv3x3_bf16": (_i32, [C.POINTER(dk_conv_desc), _vp]),
+    "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dk_ln_modulate_bf16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dk_qk_norm_rope_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
+    "dk_rope_table_f32": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i32), _i32, _f32, _vp]),
+    "dk_timestep_embedding_bf16": (_i32, [_vp, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "dk_latent_to_tokens": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dk_euler_cfg_step": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "dk_affine_f32": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "dk_groupnorm_scratch_floats": (_sz, [_i32, _i32]),
+    "dk_groupnorm_bf16": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp]),
+    "dk_softmax_rows_bf16": (_i32, [_vp, _i32, _i32, _i32, _vp]),
+    "dk_transpose_bf16": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "dk_mmdit_create": (_i32, [C.POINTER(dk_mmdit_config), C.POINTER(_vp)]),
+    "dk_mmdit_destroy": (None, [_vp]),
+    "dk_mmdit_bind": (_i32, [_vp, C.c_char_p, _vp]),
+    "dk_mmdit_mod_rows": (_i32, [_vp]),
+    "dk_mmdit_mod_offset": (_i32, [_vp, _i32, _i32]),
+    "dk_mmdit_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32, _i32]),
+    "dk_mmdit_prepare": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "dk_mmdit_cache_modulation_params": (_i32, [_vp, _vp, _fp, _i32, _vp]),
+    "dk_mmdit_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "dk_mmdit_debug_buffer": (_vp, [_vp, _i32]),
+    "dk_vae_create": (_i32, [C.POINTER(dk_vae_config), C.POINTER(_vp)]),
+    "dk_vae_destroy": (None, [_vp]),
+    "dk_vae_bind": (_i32, [_vp, C.c_char_p, _vp]),
+    "dk_vae_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "dk_vae_decode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libdk_hip.so, failing loudly if it has not been built
+    (``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C diffusionkit_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DkHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU fallback. "
+            "Run `make -C diffusionkit_amd/csrc` (needs hipcc, cross-compiles for gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise DkHipError(f"{LIB_PATH} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dk_abi_version() != 1:
+        raise DkHipError("libdk_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dk_last_error().decode("utf-8", "replace")
+        raise DkHipError(f"{what or 'dk call'} failed (rc={rc}): {msg}")

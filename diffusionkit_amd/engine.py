@@ -1,0 +1,221 @@
+"""Host-side mirrors of the reference's model objects, backed by libdk_hip.so.
+
+``MMDiTEngine`` mirrors ``MMDiT`` (python/src/diffusionkit/mlx/mmdit.py:22-266:
+``cache_modulation_params`` / ``__call__``), ``VAEDecoderEngine`` mirrors ``VAEDecoder``
+(python/src/diffusionkit/mlx/vae.py:336-401).  PyTorch is used for device memory and
+streams only; every FLOP runs in the HIP library.  There is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .config import MMDiTConfig, PositionalEncoding, VAEDecoderConfig
+
+Tensor = torch.Tensor
+_EMBED_DTYPE = {"bfloat16": 0, "float16": 1, "float32": 2}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(t: Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise _lib.DkHipError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.DkHipError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.DkHipError(f"{name} must be contiguous")
+
+
+class MMDiTEngine:
+    """Drop-in for the reference ``MMDiT`` module on the hot path."""
+
+    def __init__(self, config: MMDiTConfig, packed_weights: Dict[str, Tensor]):
+        self.lib = _lib.load()
+        self.config = config
+        c = _lib.dk_mmdit_config()
+        c.num_heads, c.depth_multimodal, c.depth_unified = config.num_heads, config.depth_multimodal, config.depth_unified
+        c.hidden_size, c.mlp_ratio = config.hidden_size, config.mlp_ratio
+        c.vae_latent_dim, c.patch_size = config.vae_latent_dim, config.patch_size
+        c.patchify_via_reshape = int(config.patchify_via_reshape)
+        c.use_qk_norm = int(config.use_qk_norm)
+        c.use_rope = int(config.pos_embed_type == PositionalEncoding.PreSDPARope)
+        axes = list(config.rope_axes_dim or ())
+        for i, a in enumerate(axes):
+            c.rope_axes_dim[i] = a
+        c.n_rope_axes, c.rope_theta = len(axes), config.rope_theta
+        c.use_pos_embed = int(config.pos_embed_type == PositionalEncoding.LearnedInputEmbedding)
+        c.max_latent_resolution = config.max_latent_resolution
+        c.pooled_text_embed_dim = config.pooled_text_embed_dim
+        c.token_level_text_embed_dim = config.token_level_text_embed_dim
+        c.frequency_embed_dim, c.max_period = config.frequency_embed_dim, config.max_period
+        c.embed_dtype = _EMBED_DTYPE[config.dtype]
+        c.layer_norm_eps = config.layer_norm_eps
+        h = C.c_void_p()
+        _lib.check(self.lib.dk_mmdit_create(C.byref(c), C.byref(h)), "dk_mmdit_create")
+        self._h = h
+        self.weights = packed_weights  # keep the device tensors alive
+        for name, t in packed_weights.items():
+            _require_cuda(t, name, torch.bfloat16)
+            _lib.check(self.lib.dk_mmdit_bind(self._h, name.encode(), t.data_ptr()), f"bind {name}")
+        self._shape = None
+        self._ws = None
+        self._n_cached = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.dk_mmdit_destroy(self._h)
+            self._h = None
+
+    # -- shape / workspace ---------------------------------------------------------------
+    def prepare(self, batch: int, latent_size: Sequence[int], text_len: int, n_timesteps: int) -> None:
+        shape = (batch, int(latent_size[0]), int(latent_size[1]), text_len, n_timesteps)
+        if self._shape == shape:
+            return
+        nbytes = self.lib.dk_mmdit_workspace_bytes(self._h, *shape)
+        dev = next(iter(self.weights.values())).device
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.dk_mmdit_prepare(self._h, *shape, self._ws.data_ptr(), self._ws.numel(), _stream()),
+                   "dk_mmdit_prepare")
+        self._shape = shape
+        self._n_cached = 0
+
+    @property
+    def batch(self):
+        return self._shape[0]
+
+    def tokens_shape(self):
+        b, hl, wl, _, _ = self._shape
+        p = self.config.patch_size
+        return (b, (hl // p) * (wl // p), self.config.patch_dim)
+
+    def mod_rows(self) -> int:
+        return self.lib.dk_mmdit_mod_rows(self._h)
+
+    def mod_offset(self, kind: int, index: int) -> int:
+        return self.lib.dk_mmdit_mod_offset(self._h, kind, index)
+
+    # -- reference API ---------------------------------------------------------------------
+    def cache_modulation_params(self, pooled_text_embeddings: Tensor, timesteps: Sequence[float]) -> None:
+        """MMDiT.cache_modulation_params (mmdit.py:77-180); ``timesteps`` are host floats
+        already rounded to the activation dtype (quirk Q1)."""
+        if self._shape is None:
+            raise _lib.DkHipError("prepare() must be called before cache_modulation_params()")
+        pooled = pooled_text_embeddings.to(torch.bfloat16).contiguous()
+        _require_cuda(pooled, "pooled_text_embeddings")
+        if pooled.shape != (self._shape[0], self.config.pooled_text_embed_dim):
+            raise _lib.DkHipError(f"pooled_text_embeddings shape {tuple(pooled.shape)} != (batch, pooled_dim)")
+        ts = [float(t) for t in timesteps]
+        arr = (C.c_float * len(ts))(*ts)
+        _lib.check(self.lib.dk_mmdit_cache_modulation_params(self._h, pooled.data_ptr(), arr, len(ts), _stream()),
+                   "dk_mmdit_cache_modulation_params")
+        self._pooled_keepalive = pooled
+        self._n_cached = len(ts)
+
+    def forward_tokens(self, tokens_in: Tensor, text: Tensor, step_index: int, tokens_out: Optional[Tensor] = None) -> Tensor:
+        """MMDiT.__call__ between patchify and unpatchify (mmdit.py:188-252)."""
+        _require_cuda(tokens_in, "tokens_in", torch.bfloat16)
+        _require_cuda(text, "text", torch.bfloat16)
+        if tuple(tokens_in.shape) != self.tokens_shape():
+            raise _lib.DkHipError(f"tokens_in shape {tuple(tokens_in.shape)} != {self.tokens_shape()}")
+        if tuple(text.shape) != (self._shape[0], self._shape[3], self.config.token_level_text_embed_dim):
+            raise _lib.DkHipError(f"text shape {tuple(text.shape)} does not match the prepared problem")
+        if not (0 <= step_index < self._n_cached):
+            raise KeyError(f"no cached modulation parameters for step {step_index}")  # reference: dict KeyError
+        if tokens_out is None:
+            tokens_out = torch.empty_like(tokens_in)
+        _lib.check(self.lib.dk_mmdit_forward(self._h, tokens_in.data_ptr(), text.data_ptr(), step_index,
+                                             tokens_out.data_ptr(), _stream()), "dk_mmdit_forward")
+        return tokens_out
+
+    def patchify(self, latent: Tensor, dup: int = 1) -> Tensor:
+        """LatentImageAdapter reshape (mmdit.py:292-300): f32 NHWC -> bf16 tokens."""
+        _require_cuda(latent, "latent", torch.float32)
+        n, hl, wl, c = latent.shape
+        p = self.config.patch_size
+        tok = torch.empty(n * dup, (hl // p) * (wl // p), p * p * c, dtype=torch.bfloat16, device=latent.device)
+        _lib.check(self.lib.dk_latent_to_tokens(latent.data_ptr(), tok.data_ptr(), n, dup, hl, wl, c, p,
+                                                int(self.config.patchify_via_reshape), _stream()), "dk_latent_to_tokens")
+        return tok
+
+    def __call__(self, latent_image_embeddings: Tensor, token_level_text_embeddings: Tensor, step_index: int) -> Tensor:
+        """MMDiT.__call__ (mmdit.py:188-266) for NHWC latents; returns tokens-major FinalLayer
+        output un-patchified to NHWC bf16 (used by parity tests; the step loop stays fused)."""
+        lat = latent_image_embeddings.to(torch.float32).contiguous()
+        tok = self.patchify(lat)
+        text = token_level_text_embeddings
+        if text.dim() == 4:  # reference passes [B, S_t, 1, T]
+            text = text.squeeze(2)
+        out = self.forward_tokens(tok, text.to(torch.bfloat16).contiguous(), step_index)
+        return unpatchify_tokens(out, self.config, lat.shape[1], lat.shape[2])
+
+
+def unpatchify_tokens(tok: Tensor, cfg: MMDiTConfig, hl: int, wl: int) -> Tensor:
+    """Pure index shuffle used only by tests / the NHWC convenience call
+    (mmdit.py:304-321, 975-988); the production step loop does this inside dk_euler_cfg_step."""
+    b = tok.shape[0]
+    p, c = cfg.patch_size, cfg.vae_latent_dim
+    h, w = hl // p, wl // p
+    if cfg.patchify_via_reshape:
+        return tok.reshape(b, h, w, c, p, p).permute(0, 1, 4, 2, 5, 3).reshape(b, hl, wl, c)
+    return tok.reshape(b, h, w, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(b, hl, wl, c)
+
+
+class VAEDecoderEngine:
+    """Drop-in for the reference ``VAEDecoder`` (+ the clip / uint8 tail)."""
+
+    def __init__(self, config: VAEDecoderConfig, packed_weights: Dict[str, Tensor]):
+        self.lib = _lib.load()
+        self.config = config
+        c = _lib.dk_vae_config()
+        c.in_channels, c.out_channels = config.in_channels, config.out_channels
+        for i, ch in enumerate(config.block_out_channels):
+            c.block_out_channels[i] = ch
+        c.n_blocks = len(config.block_out_channels)
+        c.layers_per_block, c.resnet_groups = config.layers_per_block, config.resnet_groups
+        c.group_norm_eps = config.group_norm_eps
+        h = C.c_void_p()
+        _lib.check(self.lib.dk_vae_create(C.byref(c), C.byref(h)), "dk_vae_create")
+        self._h = h
+        self.weights = packed_weights
+        for name, t in packed_weights.items():
+            _require_cuda(t, name, torch.bfloat16)
+            _lib.check(self.lib.dk_vae_bind(self._h, name.encode(), t.data_ptr()), f"bind {name}")
+        self._ws = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.dk_vae_destroy(self._h)
+            self._h = None
+
+    def decode(self, x: Tensor, want_raw: bool = False):
+        """x: f32 [B,h,w,16] -> (image f32 [B,8h,8w,3] in [0,1], uint8 image, raw bf16 or None)."""
+        x = x.to(torch.float32).contiguous()
+        _require_cuda(x, "latent")
+        b, h, w, _ = x.shape
+        nbytes = self.lib.dk_vae_workspace_bytes(self._h, b, h, w)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        scale = 2 ** (len(self.config.block_out_channels) - 1)
+        img = torch.empty(b, h * scale, w * scale, 3, dtype=torch.float32, device=x.device)
+        u8 = torch.empty(b, h * scale, w * scale, 3, dtype=torch.uint8, device=x.device)
+        raw = torch.empty(b, h * scale, w * scale, 4, dtype=torch.bfloat16, device=x.device) if want_raw else None
+        _lib.check(self.lib.dk_vae_decode(self._h, x.data_ptr(), b, h, w, img.data_ptr(), u8.data_ptr(), _ptr(raw),
+                                          self._ws.data_ptr(), self._ws.numel(), _stream()), "dk_vae_decode")
+        return img, u8, raw
+
+    def __call__(self, x: Tensor) -> Tensor:
+        """VAEDecoder.__call__ (vae.py:386-401): returns the un-clipped decoder output [B,8h,8w,3]."""
+        _, _, raw = self.decode(x, want_raw=True)
+        return raw[..., :3]

@@ -1,0 +1,165 @@
+"""Operator-level Python wrappers over the C ABI (include/dk_hip.h).
+
+Each function is a thin argument marshaller: tensors must already be on the GPU, bf16
+(unless stated) and contiguous; the call is enqueued on the current stream.  They mirror one
+MLX op of the reference hot path each and are what the parity tests drive.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (DK_EPI_BIAS, DK_EPI_BIAS_GELU, DK_EPI_BIAS_SILU, DK_EPI_GATE_RES, DK_EPI_RES)  # noqa: F401
+from .engine import _ptr, _require_cuda, _stream
+
+Tensor = torch.Tensor
+BF = torch.bfloat16
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: int = DK_EPI_BIAS,
+           gate: Optional[Tensor] = None, res: Optional[Tensor] = None, gate_seg_len: int = 0,
+           alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """nn.Linear (+ fused epilogue).  x: [M, K]; w: [N, K]; gate: [n_batch, N]; res: [M, N]."""
+    lib = _lib.load()
+    for n, t in (("x", x), ("w", w)):
+        _require_cuda(t, n, BF)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF, device=x.device)
+    d = _lib.dk_gemm_desc()
+    d.A, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.gate, d.res = _ptr(bias), _ptr(gate), _ptr(res)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldc, d.ldr = x.stride(0), out.stride(0), (res.stride(0) if res is not None else 0)
+    d.gate_seg_len = gate_seg_len
+    d.gate_stride = gate.stride(0) if gate is not None else 0
+    d.alpha, d.epilogue = alpha, epilogue
+    _lib.check(lib.dk_gemm_bf16(C.byref(d), _stream()), "dk_gemm_bf16")
+    return out
+
+
+def gemm_desc_call(**kw) -> None:
+    """Raw descriptor call (segment mappings etc.); keyword names = dk_gemm_desc fields,
+    tensors are converted to pointers."""
+    lib = _lib.load()
+    d = _lib.dk_gemm_desc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    _lib.check(lib.dk_gemm_bf16(C.byref(d), _stream()), "dk_gemm_bf16")
+
+
+_zero_pages = {}
+
+
+def zero_page(device) -> Tensor:
+    key = str(device)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(256, dtype=BF, device=device)
+    return _zero_pages[key]
+
+
+def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False, res: Optional[Tensor] = None) -> Tensor:
+    """nn.Conv2d k3 s1 p1 on NHWC; w: [O,3,3,C] (or flattened [O, 9C]); C multiple of 64."""
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    _require_cuda(w, "w", BF)
+    B, Hs, Ws, Cc = x.shape
+    H, W_ = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    O = w.shape[0]
+    ldy = (O + 3) // 4 * 4
+    y = torch.empty(B, H, W_, ldy, dtype=BF, device=x.device)
+    d = _lib.dk_conv_desc()
+    d.x, d.w, d.y, d.bias, d.res = x.data_ptr(), w.data_ptr(), y.data_ptr(), _ptr(bias), _ptr(res)
+    d.zeros = zero_page(x.device).data_ptr()
+    d.B, d.H, d.W, d.C, d.O = B, H, W_, Cc, O
+    d.ldy, d.ldr = ldy, (res.shape[-1] if res is not None else 0)
+    d.upsample = int(upsample)
+    d.epilogue = DK_EPI_RES if res is not None else DK_EPI_BIAS
+    _lib.check(lib.dk_conv3x3_bf16(C.byref(d), _stream()), "dk_conv3x3_bf16")
+    return y[..., :O]
+
+
+def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None) -> Tensor:
+    """SDPA over a token-major [B, S, 3*H*D] projection buffer -> [B, S, H*D]."""
+    lib = _lib.load()
+    _require_cuda(qkv, "qkv", BF)
+    B, S, ld = qkv.shape
+    h = H * D
+    out = torch.empty(B, S, h, dtype=BF, device=qkv.device)
+    scale = scale if scale is not None else 1.0 / math.sqrt(D)
+    base = qkv.data_ptr()
+    _lib.check(lib.dk_attention_bf16(base, base + 2 * h, base + 4 * h, out.data_ptr(), B, H, S, D, ld, h, scale, _stream()),
+               "dk_attention_bf16")
+    return out
+
+
+def ln_modulate(x: Tensor, shift: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
+    """x: [B, S, h]; shift/scale: [B, h] -> [B, S, h]."""
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    B, S, h = x.shape
+    out = torch.empty_like(x)
+    _lib.check(lib.dk_ln_modulate_bf16(x.data_ptr(), h, out.data_ptr(), h, B * S, h, shift.data_ptr(), scale.data_ptr(),
+                                       shift.stride(0), S, B * S, 0, eps, _stream()), "dk_ln_modulate_bf16")
+    return out
+
+
+def qk_norm_rope_(qkv: Tensor, H: int, D: int, qw: Optional[Tensor], kw: Optional[Tensor],
+                  rope: Optional[Tensor], pos_off: int = 0, eps: float = 1e-6) -> Tensor:
+    """In place on qkv [B, S, 3*H*D]; rope: f32 [S_pos, D/2, 2]."""
+    lib = _lib.load()
+    _require_cuda(qkv, "qkv", BF)
+    B, S, ld = qkv.shape
+    _lib.check(lib.dk_qk_norm_rope_bf16(qkv.data_ptr(), ld, 0, H * D, B * S, H, D, _ptr(qw), _ptr(kw), eps, _ptr(rope),
+                                        S, S, pos_off, _stream()), "dk_qk_norm_rope_bf16")
+    return qkv
+
+
+def rope_table(S_txt: int, gh: int, gw: int, axes, theta: float, device) -> Tensor:
+    lib = _lib.load()
+    half = sum(a // 2 for a in axes)
+    t = torch.empty(S_txt + gh * gw, half, 2, dtype=torch.float32, device=device)
+    arr = (C.c_int32 * len(axes))(*axes)
+    _lib.check(lib.dk_rope_table_f32(t.data_ptr(), S_txt, gh, gw, arr, len(axes), float(theta), _stream()), "dk_rope_table_f32")
+    return t
+
+
+def timestep_embedding(t: Tensor, dim: int, max_period: float, embed_dtype: int) -> Tensor:
+    lib = _lib.load()
+    _require_cuda(t, "t", torch.float32)
+    out = torch.empty(t.numel(), dim, dtype=BF, device=t.device)
+    _lib.check(lib.dk_timestep_embedding_bf16(t.data_ptr(), t.numel(), dim, float(max_period), embed_dtype, out.data_ptr(),
+                                              _stream()), "dk_timestep_embedding_bf16")
+    return out
+
+
+def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool) -> Tensor:
+    """x: NHWC bf16 [B,H,W,C]."""
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    B, H, W_, Cc = x.shape
+    y = torch.empty_like(x)
+    scratch = torch.empty(lib.dk_groupnorm_scratch_floats(B, groups), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dk_groupnorm_bf16(x.data_ptr(), y.data_ptr(), B, H * W_, Cc, groups, gamma.data_ptr(), beta.data_ptr(), eps,
+                                     int(silu), scratch.data_ptr(), _stream()), "dk_groupnorm_bf16")
+    return y
+
+
+def softmax_rows_(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    _lib.check(lib.dk_softmax_rows_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), _stream()), "dk_softmax_rows_bf16")
+    return x
+
+
+def transpose(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    y = torch.empty(x.shape[1], x.shape[0], dtype=BF, device=x.device)
+    _lib.check(lib.dk_transpose_bf16(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()), "dk_transpose_bf16")
+    return y

@@ -1,0 +1,425 @@
+"""DiffusionPipeline / FluxPipeline: the reference's public API re-hosted on MI355X.
+
+Signatures, defaults, return values and error behaviour follow
+python/src/diffusionkit/mlx/__init__.py:64-594 (DiffusionPipeline), :597-671 (FluxPipeline),
+:674-719 (CFGDenoiser), :722-747 (LatentFormat), :750-788 (append_dims, to_d, sample_euler).
+Only the denoising hot path (step loop + MMDiT + latent-decode VAE) is implemented; the text
+encoders (CLIP / T5), img2img and checkpoint download are outside this build's scope
+ -- ``encode_text`` uses a pluggable encoder and otherwise deterministic
+synthetic conditioning so that ``generate_image`` stays callable end to end.
+
+All arithmetic runs in libdk_hip.so on the current HIP stream; numpy is used exactly where the
+reference uses it (the seeded noise draw, __init__.py:553-557) and for O(num_steps) schedule
+scalars.
+"""
+from __future__ import annotations
+
+import hashlib
+import logging
+import time
+from typing import Callable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import (MMDIT_CKPT, MODEL_CONFIG, T5_MAX_LENGTH, MMDiTConfig, VAEDecoderConfig)
+from .engine import MMDiTEngine, VAEDecoderEngine, _stream
+from .sampler import FluxSampler, ModelSamplingDiscreteFlow, get_sigmas, max_denoise
+from .weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
+
+logger = logging.getLogger(__name__)
+Tensor = torch.Tensor
+
+
+def _round_to_dtype(x: np.ndarray, dtype: torch.dtype) -> np.ndarray:
+    return torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dtype).to(torch.float32).numpy()
+
+
+def bytes2gigabytes(n: int) -> float:
+    """python/src/diffusionkit/utils.py:42-44"""
+    return n / 1024 ** 3
+
+
+class LatentFormat:
+    """mlx/__init__.py:722-733"""
+
+    def __init__(self):
+        self.scale_factor = 1.0
+        self.shift_factor = 0.0
+
+    def process_in(self, latent: Tensor) -> Tensor:
+        return _affine(latent, self.scale_factor, -self.shift_factor * self.scale_factor)
+
+    def process_out(self, latent: Tensor) -> Tensor:
+        return _affine(latent, 1.0 / self.scale_factor, self.shift_factor)
+
+
+class SD3LatentFormat(LatentFormat):
+    def __init__(self):
+        super().__init__()
+        self.scale_factor = 1.5305
+        self.shift_factor = 0.0609
+
+
+class FluxLatentFormat(LatentFormat):
+    def __init__(self):
+        super().__init__()
+        self.scale_factor = 0.3611
+        self.shift_factor = 0.1159
+
+
+def _affine(x: Tensor, a: float, b: float) -> Tensor:
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.dk_affine_f32(x.data_ptr(), y.data_ptr(), x.numel(), a, b, _stream()), "dk_affine_f32")
+    return y
+
+
+class DiffusionPipeline:
+    _IS_FLUX = False
+
+    def __init__(
+        self,
+        w16: bool = False,
+        shift: float = 1.0,
+        use_t5: bool = True,
+        model_version: str = "argmaxinc/mlx-stable-diffusion-3-medium",
+        low_memory_mode: bool = True,
+        a16: bool = False,
+        local_ckpt=None,
+        *,
+        device: Union[str, torch.device, None] = None,
+        mmdit_config: Optional[MMDiTConfig] = None,
+        vae_config: Optional[VAEDecoderConfig] = None,
+        weights_seed: int = 1234,
+        text_len: Optional[int] = None,
+    ):
+        _lib.load()  # fail loudly before anything else if the HIP extension is missing
+        # The MI355X build computes in bf16 end to end (BASELINE.json configs); w16/a16 are
+        # accepted for signature compatibility.
+        self.float16_dtype = torch.bfloat16
+        self.dtype = torch.bfloat16
+        self.activation_dtype = torch.bfloat16
+        self.use_t5 = use_t5
+        self.mmdit_ckpt = MMDIT_CKPT[model_version]  # KeyError on unknown versions, as the reference
+        self.low_memory_mode = low_memory_mode
+        self.model_version = model_version
+        self.local_ckpt = local_ckpt
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.mmdit_config = mmdit_config or MODEL_CONFIG[model_version]
+        self.vae_config = vae_config or VAEDecoderConfig()
+        self.weights_seed = weights_seed
+        self._text_len_override = text_len
+        self._text_encoder: Optional[Callable] = None
+        self._init_sampler(shift)
+        self.check_and_load_models()
+
+    def _init_sampler(self, shift):
+        self.sampler = ModelSamplingDiscreteFlow(shift=shift)
+        self.latent_format = SD3LatentFormat()
+        self.use_clip_g = True
+
+    # -- model loading ---------------------------------------------------------------------
+    def load_mmdit(self, only_modulation_dict: bool = False):
+        """Builds the MMDiT engine.  ``local_ckpt`` may be a dict of reference-named tensors;
+        otherwise seeded synthetic weights are used (no checkpoints exist in this environment)."""
+        cfg = self.mmdit_config
+        if isinstance(self.local_ckpt, dict) and "mmdit" in self.local_ckpt:
+            named = dict(self.local_ckpt["mmdit"])
+        else:
+            named = synth_mmdit_weights(cfg, seed=self.weights_seed, device=self.device)
+        self.mmdit = MMDiTEngine(cfg, pack_mmdit(cfg, named, self.device, consume=True))
+
+    def check_and_load_models(self):
+        if not hasattr(self, "mmdit"):
+            self.load_mmdit()
+        if not hasattr(self, "decoder"):
+            if isinstance(self.local_ckpt, dict) and "vae_decoder" in self.local_ckpt:
+                named = self.local_ckpt["vae_decoder"]
+            else:
+                named = synth_vae_weights(self.vae_config, seed=self.weights_seed + 1, device=self.device)
+            self.decoder = VAEDecoderEngine(self.vae_config, pack_vae(self.vae_config, named, self.device))
+
+    # -- text conditioning (outside the hot path) ------------------------------------------------
+    def set_text_encoder(self, fn: Callable) -> None:
+        """Plug in a callable ``fn(text, cfg_weight, negative_text) -> (conditioning, pooled)``
+        (the reference's CLIP/T5 stack, mlx/__init__.py:176-251, is not part of this build)."""
+        self._text_encoder = fn
+
+    def text_len(self) -> int:
+        if self._text_len_override is not None:
+            return self._text_len_override
+        if self._IS_FLUX:
+            return T5_MAX_LENGTH[self.model_version]
+        return 77 + (T5_MAX_LENGTH[self.model_version] if self.use_t5 else 77)
+
+    def _synthetic_conditioning(self, text: str, rows: int):
+        cfg = self.mmdit_config
+        seed = int.from_bytes(hashlib.sha256(text.encode("utf-8")).digest()[:4], "little")
+        g = torch.Generator().manual_seed(seed)
+        cond = torch.randn(rows, self.text_len(), cfg.token_level_text_embed_dim, generator=g)
+        pooled = torch.randn(rows, cfg.pooled_text_embed_dim, generator=g)
+        return cond.to(self.device, torch.bfloat16), pooled.to(self.device, torch.bfloat16)
+
+    def encode_text(self, text: str, cfg_weight: float = 7.5, negative_text: str = ""):
+        """mlx/__init__.py:197-251: returns (conditioning [2,S_t,4096], pooled [2,2048]); row 0 is the
+        prompt, row 1 the negative prompt (always present)."""
+        if self._text_encoder is not None:
+            return self._text_encoder(text, cfg_weight, negative_text)
+        c0, p0 = self._synthetic_conditioning(text, 1)
+        c1, p1 = self._synthetic_conditioning("\0neg:" + negative_text, 1)
+        return torch.cat([c0, c1], 0), torch.cat([p0, p1], 0)
+
+    # -- hot path -----------------------------------------------------------------------------
+    def denoise_latents(
+        self,
+        conditioning,
+        pooled_conditioning,
+        num_steps: int = 2,
+        cfg_weight: float = 0.0,
+        latent_size: Tuple[int, int] = (64, 64),
+        seed=None,
+        image_path: Optional[str] = None,
+        denoise: float = 1.0,
+    ):
+        """mlx/__init__.py:253-292.  ``seed`` may be a list: one image per seed is denoised in a
+        single batched step loop (data-parallel sharding hands each rank a list)."""
+        if image_path is not None:
+            raise NotImplementedError("img2img (VAE encoder) is outside this build's scope (SURVEY.md §8f f4)")
+        seed = int(time.time()) if seed is None else seed
+        seeds = list(seed) if isinstance(seed, (list, tuple)) else [seed]
+        logger.info(f"Seed: {seeds}")
+        denoise = 1.0
+        x_T = self.get_empty_latent(*latent_size)
+        noise = np.concatenate([self.get_noise(s, x_T) for s in seeds], axis=0)
+        sigmas = self.get_sigmas(self.sampler, num_steps)
+        sigmas = sigmas[int(num_steps * (1 - denoise)):]
+        extra_args = {
+            "conditioning": conditioning,
+            "cfg_weight": cfg_weight,
+            "pooled_conditioning": pooled_conditioning,
+        }
+        noise_scaled = self.sampler.noise_scaling(np.float32(sigmas[0]), noise, x_T, self.max_denoise(sigmas))
+        x0 = torch.from_numpy(np.ascontiguousarray(noise_scaled, dtype=np.float32)).to(self.device)
+        latent, iter_time = sample_euler(CFGDenoiser(self), x0, sigmas, extra_args=extra_args)
+        latent = self.latent_format.process_out(latent)
+        return latent, iter_time
+
+    def generate_image(
+        self,
+        text: str,
+        num_steps: int = 2,
+        cfg_weight: float = 0.0,
+        negative_text: str = "",
+        latent_size: Tuple[int, int] = (64, 64),
+        seed=None,
+        verbose: bool = True,
+        image_path: Optional[str] = None,
+        denoise: float = 1.0,
+    ):
+        """mlx/__init__.py:294-534: returns (PIL.Image, log)."""
+        assert latent_size[0] % 2 == 0, f"Height must be divisible by 16 ({latent_size[0]*8}/16={latent_size[0]/2})"
+        assert latent_size[1] % 2 == 0, f"Width must be divisible by 16 ({latent_size[1]*8}/16={latent_size[1]/2})"
+        self.check_and_load_models()
+        start_time = time.time()
+        dev = self.device
+
+        def mem():
+            return {"peak_memory": round(bytes2gigabytes(torch.cuda.max_memory_allocated(dev)), 3),
+                    "active_memory": round(bytes2gigabytes(torch.cuda.memory_allocated(dev)), 3)}
+
+        log = {
+            "text_encoding": {"pre": mem(), "post": {"peak_memory": None, "active_memory": None}},
+            "denoising": {"pre": {"peak_memory": None, "active_memory": None}, "post": {"peak_memory": None, "active_memory": None}},
+            "decoding": {"pre": {"peak_memory": None, "active_memory": None}, "post": {"peak_memory": None, "active_memory": None}},
+            "peak_memory": 0.0,
+        }
+        t0 = time.time()
+        conditioning, pooled_conditioning = self.encode_text(text, cfg_weight, negative_text)
+        torch.cuda.synchronize(dev)
+        log["text_encoding"]["post"] = mem()
+        log["text_encoding"]["time"] = round(time.time() - t0, 3)
+        log["text_encoding"]["synthetic"] = self._text_encoder is None
+        log["peak_memory"] = max(log["peak_memory"], log["text_encoding"]["post"]["peak_memory"])
+
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.time()
+        log["denoising"]["pre"] = mem()
+        latents, iter_time = self.denoise_latents(
+            conditioning, pooled_conditioning, num_steps=num_steps, cfg_weight=cfg_weight,
+            latent_size=latent_size, seed=seed, image_path=image_path, denoise=denoise)
+        torch.cuda.synchronize(dev)
+        log["denoising"]["post"] = mem()
+        log["peak_memory"] = max(log["peak_memory"], log["denoising"]["post"]["peak_memory"])
+        log["denoising"]["time"] = round(time.time() - t0, 3)
+        log["denoising"]["iter_time"] = iter_time
+
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.time()
+        log["decoding"]["pre"] = mem()
+        _, u8, _ = self.decoder.decode(latents)
+        torch.cuda.synchronize(dev)
+        log["decoding"]["post"] = mem()
+        log["peak_memory"] = max(log["peak_memory"], log["decoding"]["post"]["peak_memory"])
+        log["decoding"]["time"] = round(time.time() - t0, 3)
+
+        if verbose:
+            logger.info("============= Summary =============")
+            logger.info(f"Text encoder: {log['text_encoding']['time']:.1f}s")
+            logger.info(f"Denoising: {log['denoising']['time']:.1f}s")
+            logger.info(f"Image decoder: {log['decoding']['time']:.1f}s")
+            logger.info(f"Peak memory: {log['peak_memory']:.1f}GB")
+
+        # reference: mx.concatenate(decoded, axis=0) stacks a batch vertically (:525)
+        x = u8.reshape(-1, u8.shape[2], 3).cpu().numpy()
+        log["total_time"] = round(time.time() - start_time, 3)
+        from PIL import Image
+        return Image.fromarray(x), log
+
+    # -- helpers (same names as the reference) ----------------------------------------------
+    def get_noise(self, seed, x_T):
+        """mlx/__init__.py:553-557: numpy global RNG, drawn NCHW, returned NHWC (float32)."""
+        np.random.seed(seed)
+        noise = np.random.randn(*x_T.transpose(0, 3, 1, 2).shape)
+        return noise.astype(np.float32).transpose(0, 2, 3, 1)
+
+    def get_sigmas(self, sampler, num_steps: int):
+        return get_sigmas(sampler, num_steps)
+
+    def get_empty_latent(self, *shape):
+        return np.ones([1, *shape, 16], dtype=np.float32) * np.float32(0.0609)
+
+    def max_denoise(self, sigmas):
+        return max_denoise(self.sampler, sigmas)
+
+    def decode_latents_to_image(self, x_t):
+        """mlx/__init__.py:581-584: float image in [0,1], NHWC."""
+        img, _, _ = self.decoder.decode(x_t)
+        return img
+
+
+class FluxPipeline(DiffusionPipeline):
+    _IS_FLUX = True
+
+    def __init__(
+        self,
+        w16: bool = False,
+        shift: float = 1.0,
+        use_t5: bool = True,
+        model_version: str = "argmaxinc/mlx-FLUX.1-schnell",
+        low_memory_mode: bool = True,
+        a16: bool = False,
+        local_ckpt=None,
+        quantize_mmdit: bool = False,
+        **kw,
+    ):
+        self.quantize_mmdit = quantize_mmdit
+        super().__init__(w16=w16, shift=shift, use_t5=True, model_version=model_version,
+                         low_memory_mode=low_memory_mode, a16=a16, local_ckpt=local_ckpt, **kw)
+
+    def _init_sampler(self, shift):
+        self.sampler = FluxSampler(shift=shift)
+        self.latent_format = FluxLatentFormat()
+        self.use_t5 = True
+        self.use_clip_g = False
+
+    def encode_text(self, text: str, cfg_weight: float = 7.5, negative_text: str = ""):
+        """mlx/__init__.py:642-671: FLUX ignores the negative prompt, batch 1."""
+        if self._text_encoder is not None:
+            return self._text_encoder(text, cfg_weight, negative_text)
+        return self._synthetic_conditioning(text, 1)
+
+
+class CFGDenoiser:
+    """mlx/__init__.py:674-719"""
+
+    def __init__(self, model: DiffusionPipeline):
+        self.model = model
+        self._timesteps: List[float] = []
+
+    def cache_modulation_params(self, pooled_text_embeddings, timesteps):
+        self._timesteps = [float(t) for t in timesteps]
+        self.model.mmdit.cache_modulation_params(pooled_text_embeddings, self._timesteps)
+
+    def clear_cache(self):
+        # the reference re-reads the adaLN weights from disk here (:686-689); they stay resident
+        # in HBM in this build, so there is nothing to do.
+        pass
+
+    def step_index(self, timestep: float) -> int:
+        return self._timesteps.index(float(timestep))  # first match, like the reference's dict key (Q11)
+
+    def __call__(self, x_t, timestep, sigma, conditioning, cfg_weight: float = 7.5, pooled_conditioning=None):
+        """Returns the (CFG-combined) x0 prediction, fp32, same shape as x_t."""
+        mm = self.model.mmdit
+        cfg_on = cfg_weight > 0
+        tok = mm.patchify(x_t.contiguous(), dup=2 if cfg_on else 1)
+        out = mm.forward_tokens(tok, conditioning, self.step_index(timestep))
+        den = x_t.clone()
+        _euler(self.model, den, out, tok, cfg_on, float(sigma), 0.0, float(cfg_weight))  # x + d*(0 - sigma) = x0
+        return den
+
+
+def _euler(pipe, x, model_out, tok, cfg_on, sigma, sigma_next, cfg_weight):
+    cfg = pipe.mmdit_config
+    n_img, hl, wl, c = x.shape
+    lib = _lib.load()
+    _lib.check(lib.dk_euler_cfg_step(x.data_ptr(), model_out.data_ptr(), model_out.shape[-1], tok.data_ptr(), n_img,
+                                     int(cfg_on), hl, wl, c, cfg.patch_size, int(cfg.patchify_via_reshape),
+                                     sigma, sigma_next, cfg_weight, _stream()), "dk_euler_cfg_step")
+
+
+def append_dims(x, target_dims):
+    """mlx/__init__.py:750-753"""
+    dims_to_append = target_dims - x.ndim
+    return x[(...,) + (None,) * dims_to_append]
+
+
+def to_d(x, sigma, denoised):
+    """mlx/__init__.py:756-758"""
+    return (x - denoised) / sigma
+
+
+def sample_euler(model: CFGDenoiser, x: Tensor, sigmas, extra_args=None):
+    """mlx/__init__.py:761-788.  x: fp32 [n_img,h,w,16] on the GPU (updated copy is returned);
+    sigmas: host float32 array.  One device synchronisation per step (the reference's
+    mx.eval(x)) provides iter_time."""
+    extra_args = {} if extra_args is None else dict(extra_args)
+    pipe = model.model
+    mm = pipe.mmdit
+    sigmas = np.asarray(sigmas, dtype=np.float32)
+    cfg_weight = float(extra_args.get("cfg_weight", 7.5))
+    cfg_on = cfg_weight > 0
+    conditioning = extra_args["conditioning"]
+    pooled = extra_args.pop("pooled_conditioning")
+    if conditioning.dim() == 4:
+        conditioning = conditioning.squeeze(2)
+    n_img = x.shape[0]
+    rows = n_img * (2 if cfg_on else 1)
+    if not cfg_on and conditioning.shape[0] != rows:
+        # SD3 with CFG off: the reference cannot run this; use the prompt row(s).
+        conditioning, pooled = conditioning[:rows], pooled[:rows]
+    if conditioning.shape[0] != rows or pooled.shape[0] != rows:
+        raise ValueError(f"conditioning batch {conditioning.shape[0]} does not match latent batch {rows}")
+    conditioning = conditioning.to(pipe.device, torch.bfloat16).contiguous()
+    pooled = pooled.to(pipe.device, torch.bfloat16).contiguous()
+
+    # model timesteps are sigma*1000 rounded to the activation dtype (quirk Q1)
+    timesteps = _round_to_dtype(pipe.sampler.timestep(sigmas), pipe.activation_dtype)
+    mm.prepare(rows, x.shape[1:3], conditioning.shape[1], len(timesteps))
+    model.cache_modulation_params(pooled, timesteps)
+
+    x = x.to(torch.float32).contiguous().clone()
+    tok = mm.patchify(x, dup=2 if cfg_on else 1)
+    out = torch.empty_like(tok)
+    iter_time = []
+    for i in range(len(sigmas) - 1):
+        t0 = time.perf_counter()
+        mm.forward_tokens(tok, conditioning, i, tokens_out=out)
+        _euler(pipe, x, out, tok, cfg_on, float(sigmas[i]), float(sigmas[i + 1]), cfg_weight)
+        torch.cuda.synchronize(pipe.device)
+        iter_time.append(round(time.perf_counter() - t0, 3))
+    model.clear_cache()
+    return x, iter_time

@@ -1,0 +1,237 @@
+"""Weights of the hot path: synthetic initialisation and packing into the device layout.
+
+There is no network / checkpoint in this environment, so benchmarks and parity tests use
+seeded random weights with the shapes of the reference's module tree
+(Linear/Conv weights N(0, 0.02^2), biases N(0, 0.02^2),
+norm gains 1 + N(0, 0.02^2)).  Tensor names follow the reference's MLX module tree after
+``model_io`` remapping (python/src/diffusionkit/mlx/model_io.py:130-311, 314-408, 411-486),
+so a real checkpoint loader ("next" row f1) only has to produce the same dict.
+
+``pack_mmdit`` / ``pack_vae`` turn that dict into the fused, K-major bf16 tensors the HIP
+engine binds by name:
+  * q/k/v projections -> one [3h, h] matrix, bias [3h] with a zero k part (quirk Q9);
+  * single blocks: o_proj | fc2 -> linear2 [h, 5h] with ONE bias (quirk Q8);
+  * all adaLN_modulation Linears -> one [rows*h, h] matrix in the engine's row order;
+  * conv weights [O,3,3,I] -> [O, 9*I] (already K-major in the MLX layout), conv_in padded to I=64.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import MMDiTConfig, VAEDecoderConfig
+
+Tensor = torch.Tensor
+
+
+def _gen(device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+class _Init:
+    def __init__(self, device, seed, dtype):
+        self.device, self.dtype = torch.device(device), dtype
+        self.g = _gen(self.device, seed)
+        self.out: Dict[str, Tensor] = {}
+
+    def normal(self, name, shape, std=0.02, mean=0.0):
+        t = torch.randn(*shape, generator=self.g, device=self.device, dtype=torch.float32) * std + mean
+        self.out[name] = t.to(self.dtype)
+
+    def linear(self, prefix, out_f, in_f, bias=True):
+        self.normal(prefix + ".weight", (out_f, in_f))
+        if bias:
+            self.normal(prefix + ".bias", (out_f,))
+
+
+def synth_mmdit_weights(cfg: MMDiTConfig, seed: int = 1234, device="cpu", dtype=torch.bfloat16) -> Dict[str, Tensor]:
+    """Random weights keyed like the reference MMDiT module tree (mmdit.py:22-75)."""
+    I = _Init(device, seed, dtype)
+    h, D, r = cfg.hidden_size, cfg.head_dim, cfg.mlp_ratio
+    p = cfg.patch_size
+    if cfg.patchify_via_reshape:
+        I.normal("x_embedder.proj.weight", (h, 1, 1, cfg.patch_dim))
+    else:
+        I.normal("x_embedder.proj.weight", (h, p, p, cfg.vae_latent_dim))
+    I.normal("x_embedder.proj.bias", (h,))
+    if cfg.rope_axes_dim is None:
+        I.normal("x_pos_embedder.pos_embed.weight", (cfg.max_latent_resolution ** 2, h))
+    for emb, d_in in (("y_embedder", cfg.pooled_text_embed_dim), ("t_embedder", cfg.frequency_embed_dim)):
+        I.linear(f"{emb}.mlp.layers.0", h, d_in)
+        I.linear(f"{emb}.mlp.layers.2", h, h)
+    I.linear("context_embedder", h, cfg.token_level_text_embed_dim)
+
+    def block(prefix, n_mod, skip_post=False, parallel=False):
+        I.linear(prefix + ".attn.q_proj", h, h)
+        I.linear(prefix + ".attn.k_proj", h, h, bias=False)
+        I.linear(prefix + ".attn.v_proj", h, h)
+        if cfg.use_qk_norm:
+            I.normal(prefix + ".qk_norm.q_norm.weight", (D,), mean=1.0)
+            I.normal(prefix + ".qk_norm.k_norm.weight", (D,), mean=1.0)
+        if not skip_post:
+            I.linear(prefix + ".attn.o_proj", h, h)
+            I.linear(prefix + ".mlp.fc1", r * h, h)
+            I.linear(prefix + ".mlp.fc2", h, r * h, bias=not parallel)
+        I.linear(prefix + ".adaLN_modulation.layers.1", n_mod * h, h)
+
+    for i in range(cfg.depth_multimodal):
+        skip_txt = (i == cfg.depth_multimodal - 1) and cfg.depth_unified < 1
+        block(f"multimodal_transformer_blocks.{i}.image_transformer_block", 6)
+        block(f"multimodal_transformer_blocks.{i}.text_transformer_block", 2 if skip_txt else 6, skip_post=skip_txt)
+    for i in range(cfg.depth_unified):
+        block(f"unified_transformer_blocks.{i}.transformer_block", 3, parallel=True)
+    I.linear("final_layer.linear", cfg.patch_dim, h)
+    I.linear("final_layer.adaLN_modulation.layers.1", 2 * h, h)
+    return I.out
+
+
+def synth_vae_weights(cfg: VAEDecoderConfig, seed: int = 4321, device="cpu", dtype=torch.bfloat16) -> Dict[str, Tensor]:
+    """Random weights keyed like the reference VAEDecoder module tree (vae.py:336-384)."""
+    I = _Init(device, seed, dtype)
+
+    def conv(prefix, o, i):
+        I.normal(prefix + ".weight", (o, 3, 3, i))
+        I.normal(prefix + ".bias", (o,))
+
+    def norm(prefix, c):
+        I.normal(prefix + ".weight", (c,), mean=1.0)
+        I.normal(prefix + ".bias", (c,))
+
+    def resnet(prefix, cin, cout):
+        norm(prefix + ".norm1", cin)
+        conv(prefix + ".conv1", cout, cin)
+        norm(prefix + ".norm2", cout)
+        conv(prefix + ".conv2", cout, cout)
+        if cin != cout:
+            I.linear(prefix + ".conv_shortcut", cout, cin)
+
+    boc = list(cfg.block_out_channels)
+    cm = boc[-1]
+    conv("conv_in", cm, cfg.in_channels)
+    resnet("mid_blocks.0", cm, cm)
+    norm("mid_blocks.1.group_norm", cm)
+    for n in ("query_proj", "key_proj", "value_proj", "out_proj"):
+        I.linear(f"mid_blocks.1.{n}", cm, cm)
+    resnet("mid_blocks.2", cm, cm)
+    cprev = cm
+    for j in reversed(range(len(boc))):  # execution order: list index n-1 ... 0 (vae.py:379,393)
+        cout = boc[j]
+        for rr in range(cfg.layers_per_block):
+            resnet(f"up_blocks.{j}.resnets.{rr}", cprev if rr == 0 else cout, cout)
+        if j > 0:
+            conv(f"up_blocks.{j}.upsample", cout, cout)
+        cprev = cout
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", cfg.out_channels, boc[0])
+    return I.out
+
+
+# ---------------------------------------------------------------------------------------------
+# packing
+# ---------------------------------------------------------------------------------------------
+def adaln_order(cfg: MMDiTConfig):
+    """Module order of the packed adaLN matrix = engine modulation-table row order
+    (dk_mmdit_mod_offset): per double block image(6) then text(6|2), singles(3), final(2)."""
+    names = []
+    for i in range(cfg.depth_multimodal):
+        names.append(f"multimodal_transformer_blocks.{i}.image_transformer_block")
+        names.append(f"multimodal_transformer_blocks.{i}.text_transformer_block")
+    for i in range(cfg.depth_unified):
+        names.append(f"unified_transformer_blocks.{i}.transformer_block")
+    names.append("final_layer")
+    return names
+
+
+def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = False) -> Dict[str, Tensor]:
+    """Reference-named weights -> engine tensors (bf16, contiguous, on ``device``).
+    ``consume=True`` pops source tensors as they are packed (halves peak memory at full size)."""
+    dev = torch.device(device)
+    bf = torch.bfloat16
+    out: Dict[str, Tensor] = {}
+    get = (lambda k: w.pop(k)) if consume else (lambda k: w[k])
+
+    def put(name, t):
+        out[name] = t.to(device=dev, dtype=bf).contiguous()
+
+    xw = get("x_embedder.proj.weight")
+    put("x_embedder.proj.weight", xw.reshape(xw.shape[0], -1))
+    put("x_embedder.proj.bias", get("x_embedder.proj.bias"))
+    if "x_pos_embedder.pos_embed.weight" in w:
+        put("x_pos_embedder.pos_embed.weight", get("x_pos_embedder.pos_embed.weight"))
+    for k in ("context_embedder.weight", "context_embedder.bias",
+              "y_embedder.mlp.layers.0.weight", "y_embedder.mlp.layers.0.bias",
+              "y_embedder.mlp.layers.2.weight", "y_embedder.mlp.layers.2.bias",
+              "t_embedder.mlp.layers.0.weight", "t_embedder.mlp.layers.0.bias",
+              "t_embedder.mlp.layers.2.weight", "t_embedder.mlp.layers.2.bias",
+              "final_layer.linear.weight", "final_layer.linear.bias"):
+        put(k, get(k))
+
+    put("adaLN.weight", torch.cat([get(n + ".adaLN_modulation.layers.1.weight").to(dev) for n in adaln_order(cfg)], dim=0))
+    put("adaLN.bias", torch.cat([get(n + ".adaLN_modulation.layers.1.bias").to(dev) for n in adaln_order(cfg)], dim=0))
+
+    def stream(prefix, single=False, skip_post=False):
+        q, k, v = (get(f"{prefix}.attn.{n}_proj.weight").to(dev) for n in "qkv")
+        put(prefix + ".attn.qkv.weight", torch.cat([q, k, v], dim=0))
+        qb, vb = get(f"{prefix}.attn.q_proj.bias").to(dev), get(f"{prefix}.attn.v_proj.bias").to(dev)
+        put(prefix + ".attn.qkv.bias", torch.cat([qb, torch.zeros_like(qb), vb], dim=0))
+        if cfg.use_qk_norm:
+            put(prefix + ".qk_norm.q_norm.weight", get(prefix + ".qk_norm.q_norm.weight"))
+            put(prefix + ".qk_norm.k_norm.weight", get(prefix + ".qk_norm.k_norm.weight"))
+        if skip_post:
+            return
+        put(prefix + ".mlp.fc1.weight", get(prefix + ".mlp.fc1.weight"))
+        put(prefix + ".mlp.fc1.bias", get(prefix + ".mlp.fc1.bias"))
+        if single:
+            put(prefix + ".linear2.weight",
+                torch.cat([get(prefix + ".attn.o_proj.weight").to(dev), get(prefix + ".mlp.fc2.weight").to(dev)], dim=1))
+            put(prefix + ".linear2.bias", get(prefix + ".attn.o_proj.bias"))
+        else:
+            for n in ("attn.o_proj", "mlp.fc2"):
+                put(f"{prefix}.{n}.weight", get(f"{prefix}.{n}.weight"))
+                put(f"{prefix}.{n}.bias", get(f"{prefix}.{n}.bias"))
+
+    for i in range(cfg.depth_multimodal):
+        skip_txt = (i == cfg.depth_multimodal - 1) and cfg.depth_unified < 1
+        stream(f"multimodal_transformer_blocks.{i}.image_transformer_block")
+        stream(f"multimodal_transformer_blocks.{i}.text_transformer_block", skip_post=skip_txt)
+    for i in range(cfg.depth_unified):
+        stream(f"unified_transformer_blocks.{i}.transformer_block", single=True)
+    return out
+
+
+def pack_vae(cfg: VAEDecoderConfig, w: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+    dev = torch.device(device)
+    out: Dict[str, Tensor] = {}
+    for k, t in w.items():
+        t = t.to(dev)
+        if k == "conv_in.weight":  # pad input channels to 64 for the implicit-GEMM K tiling
+            o, kh, kw, i = t.shape
+            tp = torch.zeros(o, kh, kw, 64, dtype=t.dtype, device=dev)
+            tp[..., :i] = t
+            t = tp
+        if t.dim() == 4:
+            t = t.reshape(t.shape[0], -1)
+        out[k] = t.to(torch.bfloat16).contiguous()
+    return out
+
+
+def blob_pack(tensors: Dict[str, Tensor]):
+    """Flatten a tensor dict into one contiguous bf16 blob + index (for a single RCCL broadcast)."""
+    index, off = [], 0
+    for k in sorted(tensors):
+        t = tensors[k]
+        n = t.numel()
+        index.append((k, tuple(t.shape), off, n))
+        off += (n + 127) // 128 * 128  # keep every tensor 256-byte aligned
+    dev = next(iter(tensors.values())).device
+    blob = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+    for k, shape, o, n in index:
+        blob[o:o + n] = tensors[k].reshape(-1)
+    return blob, index
+
+
+def blob_unpack(blob: Tensor, index) -> Dict[str, Tensor]:
+    return {k: blob[o:o + n].view(*shape) for k, shape, o, n in index}

@@ -1,0 +1,126 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the header
+declares, the ctypes table covers the header, weight packing matches the engine's table layout,
+and the host classes refuse to run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from diffusionkit_amd import _lib
+from diffusionkit_amd.config import FLUX_SCHNELL, SD3_2b, tiny_flux, tiny_sd3, tiny_vae
+from diffusionkit_amd.weights import (adaln_order, blob_pack, blob_unpack, pack_mmdit, pack_vae, synth_mmdit_weights,
+                                      synth_vae_weights)
+
+
+def header_symbols():
+    src = open(_lib.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/dk_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.dk_abi_version() == 1
+
+
+def test_mod_table_layout_matches_config():
+    lib = _lib.load()
+    from diffusionkit_amd.engine import MMDiTEngine  # noqa: F401  (import only)
+    for cfg in (tiny_flux(), tiny_sd3(), FLUX_SCHNELL, SD3_2b):
+        c = _lib.dk_mmdit_config()
+        c.num_heads, c.depth_multimodal, c.depth_unified = cfg.num_heads, cfg.depth_multimodal, cfg.depth_unified
+        c.hidden_size, c.mlp_ratio, c.vae_latent_dim, c.patch_size = cfg.hidden_size, 4, 16, 2
+        c.pooled_text_embed_dim, c.token_level_text_embed_dim, c.frequency_embed_dim = 64, 64, 256
+        h = ctypes.c_void_p()
+        assert lib.dk_mmdit_create(ctypes.byref(c), ctypes.byref(h)) == 0
+        assert lib.dk_mmdit_mod_rows(h) == cfg.num_modulation_rows()
+        # offsets follow adaln_order: img(6), txt(6|2) per double block, singles(3), final(2)
+        off = 0
+        for i in range(cfg.depth_multimodal):
+            assert lib.dk_mmdit_mod_offset(h, 0, i) == off
+            off += 6
+            assert lib.dk_mmdit_mod_offset(h, 1, i) == off
+            off += 2 if (i == cfg.depth_multimodal - 1 and cfg.depth_unified < 1) else 6
+        for i in range(cfg.depth_unified):
+            assert lib.dk_mmdit_mod_offset(h, 2, i) == off
+            off += 3
+        assert lib.dk_mmdit_mod_offset(h, 3, 0) == off
+        lib.dk_mmdit_destroy(h)
+    if FLUX_SCHNELL.num_modulation_rows() != 344:
+        raise AssertionError("FLUX modulation rows must be 19*12 + 38*3 + 2 = 344 (SURVEY.md §8a a6)")
+
+
+def test_create_rejects_bad_config():
+    lib = _lib.load()
+    c = _lib.dk_mmdit_config()
+    c.num_heads, c.hidden_size, c.patch_size, c.vae_latent_dim = 3, 96, 2, 16
+    h = ctypes.c_void_p()
+    assert lib.dk_mmdit_create(ctypes.byref(c), ctypes.byref(h)) != 0
+    assert b"head_dim" in lib.dk_last_error()
+
+
+def test_pack_mmdit_shapes():
+    for cfg in (tiny_flux(), tiny_sd3()):
+        w = synth_mmdit_weights(cfg)
+        n_src = len(w)
+        p = pack_mmdit(cfg, w, "cpu")
+        assert len(w) == n_src  # not consumed by default
+        h = cfg.hidden_size
+        assert p["adaLN.weight"].shape == (cfg.num_modulation_rows() * h, h)
+        assert p["x_embedder.proj.weight"].shape == (h, 64)
+        b0 = "multimodal_transformer_blocks.0.image_transformer_block"
+        assert p[b0 + ".attn.qkv.weight"].shape == (3 * h, h)
+        assert torch.all(p[b0 + ".attn.qkv.bias"][h:2 * h] == 0)  # k_proj has no bias (quirk Q9)
+        assert torch.equal(p[b0 + ".attn.qkv.weight"][h:2 * h], w[b0 + ".attn.k_proj.weight"])
+        if cfg.depth_unified:
+            s0 = "unified_transformer_blocks.0.transformer_block"
+            assert p[s0 + ".linear2.weight"].shape == (h, 5 * h)
+            assert torch.equal(p[s0 + ".linear2.weight"][:, :h], w[s0 + ".attn.o_proj.weight"])
+            assert torch.equal(p[s0 + ".linear2.bias"], w[s0 + ".attn.o_proj.bias"])  # one bias (quirk Q8)
+        first = adaln_order(cfg)[0]
+        assert torch.equal(p["adaLN.weight"][:6 * h], w[first + ".adaLN_modulation.layers.1.weight"])
+        blob, index = blob_pack(p)
+        q = blob_unpack(blob, index)
+        assert all(torch.equal(q[k], p[k]) for k in p)
+
+
+def test_pack_vae_pads_conv_in():
+    vc = tiny_vae()
+    p = pack_vae(vc, synth_vae_weights(vc), "cpu")
+    assert p["conv_in.weight"].shape == (128, 9 * 64)
+    w4 = p["conv_in.weight"].reshape(128, 3, 3, 64)
+    assert torch.all(w4[..., 16:] == 0)
+    assert p["up_blocks.1.upsample.weight"].shape == (64, 9 * 64)
+    assert "up_blocks.0.upsample.weight" not in p
+
+
+def test_no_cpu_fallback():
+    from diffusionkit_amd.engine import MMDiTEngine
+    cfg = tiny_flux()
+    packed = pack_mmdit(cfg, synth_mmdit_weights(cfg), "cpu")
+    with pytest.raises(_lib.DkHipError):
+        MMDiTEngine(cfg, packed)  # CPU tensors are rejected: the product path is HIP only
+
+
+def test_unknown_model_version_is_a_keyerror():
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    from diffusionkit_amd import pipeline
+    with pytest.raises(KeyError):
+        pipeline.DiffusionPipeline(model_version="not-a-model")
+
+
+def test_package_does_not_import_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusionkit_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,64 @@
+"""world_size-2 gloo tests of the data-parallel plumbing (no GPU): seed sharding, the single
+weight-blob broadcast and the image gather."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffusionkit_amd.dist import shard_seeds
+
+
+def test_shard_seeds_partitions():
+    seeds = list(range(64))
+    parts = [shard_seeds(seeds, r, 8) for r in range(8)]
+    assert parts[3] == list(range(24, 32))
+    assert sum(parts, []) == seeds
+    parts = [shard_seeds(list(range(10)), r, 4) for r in range(4)]
+    assert sum(parts, []) == list(range(10)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from diffusionkit_amd import dist as dk
+    from diffusionkit_amd.config import tiny_flux
+    from diffusionkit_amd.weights import pack_mmdit, synth_mmdit_weights
+    r, lr, w = dk.init_distributed("gloo")
+    cfg = tiny_flux(1, 1)
+    packed = pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=99), "cpu") if r == 0 else None
+    got = dk.broadcast_weights(packed, "cpu", src=0)
+    ref = pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=99), "cpu")
+    ok = set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+    imgs = torch.full((2, 4, 4, 3), r, dtype=torch.uint8)
+    g = dk.gather_images(imgs, dst=0)
+    if r == 0:
+        ok = ok and len(g) == w and all(int(g[i].max()) == i for i in range(w))
+    else:
+        ok = ok and g is None
+    seeds = dk.shard_seeds(list(range(8)), r, w)
+    ok = ok and seeds == list(range(4 * r, 4 * r + 4))
+    dist.barrier()
+    q.put((r, ok))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
