@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec for FLUX.1-schnell 1024x1024, 4 Euler steps, bf16, batch 1 per GPU
+(BASELINE.json configs[1]); data-parallel over N GPUs of one node (independent images, one RCCL
+weight broadcast at load, no collectives in the step loop).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic input per rank: 4 denoising steps (MMDiT
+forward + fused CFG/Euler update) followed by the VAE latent decode to a uint8 image.  Inputs
+(conditioning, weights) are resident in HBM before the timed region; the per-image noise draw is the
+reference's host numpy RNG (mlx/__init__.py:553-557) and its 1 MiB upload is inside the region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def block_flops(S, h):
+    return 24.0 * S * h * h + 4.0 * S * S * h
+
+
+def mmdit_step_flops(cfg, S_t, S_i, B):
+    """Algorithmic FLOPs (2*MAC) of one MMDiT forward, modulation excluded."""
+    h, S = cfg.hidden_size, S_t + S_i
+    f = (cfg.depth_multimodal + cfg.depth_unified) * block_flops(S, h)
+    f += 2.0 * S_t * cfg.token_level_text_embed_dim * h + 2.0 * S_i * cfg.patch_dim * h * 2
+    return B * f
+
+
+def vae_flops(vcfg, h, w):
+    """conv / linear / attention FLOPs of the decoder (vae.py:386-401)."""
+    boc = list(vcfg.block_out_channels)
+    cm = boc[-1]
+    f = 2.0 * h * w * 9 * vcfg.in_channels * cm
+    res = lambda H, W, ci, co: 2.0 * H * W * 9 * (ci * co + co * co) + (2.0 * H * W * ci * co if ci != co else 0)
+    f += 2 * res(h, w, cm, cm)
+    T = h * w
+    f += 4 * 2.0 * T * cm * cm + 4.0 * T * T * cm
+    H, W, cprev = h, w, cm
+    for j in reversed(range(len(boc))):
+        co = boc[j]
+        for r in range(vcfg.layers_per_block):
+            f += res(H, W, cprev if r == 0 else co, co)
+        cprev = co
+        if j > 0:
+            H, W = 2 * H, 2 * W
+            f += 2.0 * H * W * 9 * co * co
+    f += 2.0 * H * W * 9 * boc[0] * vcfg.out_channels
+    return f
+
+
+def cpu_baseline(cfg, S_t, S_i, num_steps, image_flops, mmdit_flops_per_step):
+    """CPU 'port' baseline: the oracle restatement timed on this box's host cores over a bounded
+    sample -- one double block + one single block of the FLUX MMDiT at the full 1024x1024 shapes
+    (S = 4352, h = 3072, fp32) -- extrapolated to the whole image by algorithmic FLOPs."""
+    import torch
+    from dataclasses import replace
+    from diffusionkit_amd.weights import synth_mmdit_weights
+    from oracle.mmdit import OracleMMDiT, Prec
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    c1 = replace(cfg, depth_multimodal=1, depth_unified=1 if cfg.depth_unified else 0)
+    w = {k: v.float() for k, v in synth_mmdit_weights(c1, seed=1).items()}
+    m = OracleMMDiT(c1, w, Prec())
+    g = torch.Generator().manual_seed(0)
+    p = cfg.patch_size
+    side = int(round(S_i ** 0.5)) * p
+    lat = torch.randn(1, side, side, 16, generator=g)
+    text = torch.randn(1, S_t, cfg.token_level_text_embed_dim, generator=g)
+    pooled = torch.randn(1, cfg.pooled_text_embed_dim, generator=g)
+    m.cache_modulation_params(pooled, torch.tensor([752.0]))
+    t0 = time.perf_counter()
+    m(lat, text, 752.0)
+    dt = time.perf_counter() - t0
+    sample_flops = mmdit_step_flops(c1, S_t, S_i, 1)
+    rate = sample_flops / dt  # FLOP/s of the port on this host
+    return {
+        "value": rate / image_flops, "unit": "images/s", "cores": cores, "kind": "port",
+        "sample": f"oracle fp32 MMDiT with 1 double + {c1.depth_unified} single block at S={S_t + S_i}, h={cfg.hidden_size} "
+                  f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {rate / 1e9:.0f} GFLOP/s), extrapolated by FLOPs to "
+                  f"{num_steps} steps + VAE ({image_flops / 1e12:.1f} TFLOP/image)",
+        "sample_seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from diffusionkit_amd import _lib
+    from diffusionkit_amd import dist as dk
+    from diffusionkit_amd.config import FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, tiny_flux, tiny_vae
+    from diffusionkit_amd.pipeline import DiffusionPipeline, FluxPipeline
+    from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
+
+    rank, local_rank, world = dk.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+
+    if args.workload == "flux-schnell-1024":
+        cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 4, 0.0, 1.0, 256, 1
+    elif args.workload == "sd3-medium-1024":
+        cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 5.0, 3.0, 589, 2
+    else:
+        cfg, vcfg, cls, mv = tiny_flux(), tiny_vae(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (16, 16), 4, 0.0, 1.0, 64, 1
+
+    # ---- weights: rank 0 creates them, one RCCL broadcast of the packed blob over xGMI ----
+    t0 = time.perf_counter()
+    packed = None
+    if rank == 0:
+        mm = pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=1234, device=dev), dev, consume=True)
+        vv = pack_vae(vcfg, synth_vae_weights(vcfg, seed=1235, device=dev), dev)
+        packed = {"mmdit/" + k: v for k, v in mm.items()}
+        packed.update({"vae/" + k: v for k, v in vv.items()})
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    packed = dk.broadcast_weights(packed, dev, src=0)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    weights = {"mmdit": {k[6:]: v for k, v in packed.items() if k.startswith("mmdit/")},
+               "vae_decoder": {k[4:]: v for k, v in packed.items() if k.startswith("vae/")}}
+    pipe = cls(w16=True, a16=True, shift=shift, model_version=mv, mmdit_config=cfg, vae_config=vcfg, device=dev,
+               text_len=S_t, packed_weights=weights)
+
+    # synthetic conditioning of the reference's shapes, resident in HBM (text encoders are out of scope)
+    g = torch.Generator().manual_seed(1 + rank)
+    cond = torch.randn(rows, S_t, cfg.token_level_text_embed_dim, generator=g).to(dev, torch.bfloat16)
+    pooled = torch.randn(rows, cfg.pooled_text_embed_dim, generator=g).to(dev, torch.bfloat16)
+
+    denoise_ms, vae_ms = [], []
+
+    def one_image(seed):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        lat, _ = pipe.denoise_latents(cond, pooled, num_steps=num_steps, cfg_weight=cfg_weight, latent_size=latent, seed=seed)
+        e1.record()
+        _, u8, _ = pipe.decoder.decode(lat)
+        e2.record()
+        return u8, (e0, e1, e2)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_image(1000 + i)
+    barrier()
+    t0 = time.perf_counter()
+    evs = []
+    for i in range(args.steps):
+        u8, ev = one_image(rank * 100000 + i)
+        evs.append(ev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for e0, e1, e2 in evs:
+        denoise_ms.append(e0.elapsed_time(e1))
+        vae_ms.append(e1.elapsed_time(e2))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events on the launch stream ----
+    S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
+    step_flops = mmdit_step_flops(cfg, S_t, S_i, rows)
+    image_flops = num_steps * step_flops + vae_flops(vcfg, *latent)
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        lib.dk_profile_enable(1)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_image(rank * 100000 + i)
+        torch.cuda.synchronize()
+        instr = time.perf_counter() - t1
+        stats = {}
+        for name, cls_id in (("gemm", 0), ("conv", 1), ("attention", 2)):
+            ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+            _lib.check(lib.dk_profile_read(cls_id, C.byref(ms), C.byref(work), C.byref(n)), "dk_profile_read")
+            stats[name] = (ms.value, work.value, n.value)
+        lib.dk_profile_enable(0)
+        ms, work, n = stats["gemm"]
+        ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        roofline = {
+            "bound": "mfma", "kernel": "dk_gemm_bf16_kernel<0>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+            "flops_per_launch": work / max(n, 1),
+            "gemm_ms_per_image": round(ms / args.steps, 2),
+            "attention": {"achieved": round(stats["attention"][1] / max(stats["attention"][0], 1e-9) / 1e9, 1),
+                          "ms_per_image": round(stats["attention"][0] / args.steps, 2), "launches": stats["attention"][2]},
+            "conv": {"achieved": round(stats["conv"][1] / max(stats["conv"][0], 1e-9) / 1e9, 1),
+                     "ms_per_image": round(stats["conv"][0] / args.steps, 2), "launches": stats["conv"][2]},
+            "instrumented_ms_per_step": round(instr / args.steps * 1e3, 2),
+            "method": "HIP events around every launch on the launch stream, replay of the timed region",
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
+        cpu = cpu_baseline(cfg, S_t, S_i, num_steps, image_flops, step_flops)
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "images/sec (whole node) FLUX.1-schnell 1024x1024 4-step" if args.workload == "flux-schnell-1024"
+                      else f"images/sec (whole node) {args.workload}",
+            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
+            "config": {"workload": f"{args.workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
+                                   f"text tokens {S_t}, batch 1 image per GPU per step, + VAE decode to uint8",
+                       "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
+            "denoise_ms_per_step": round(float(np.mean(denoise_ms)) / num_steps, 2),
+            "vae_decode_ms": round(float(np.mean(vae_ms)), 2),
+            "algorithmic_tflop_per_image": round(image_flops / 1e12, 2),
+            "mfma_roofline_frac_whole_path": round(image_flops * args.steps / elapsed / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,10 +219,12 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AttnCfg<64>::TILE_BYTES));
     attr_set = true;
   }
+  dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   if (p.D == 128)
     hipLaunchKernelGGL(dk_attn_fwd_kernel<128>, grid, block, 4 * AttnCfg<128>::TILE_BYTES, stream, p);
   else
     hipLaunchKernelGGL(dk_attn_fwd_kernel<64>, grid, block, 4 * AttnCfg<64>::TILE_BYTES, stream, p);
+  dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -33,6 +33,10 @@ struct GemmParams {
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
 
+// optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention
+void dk_prof_begin(int cls, double work, hipStream_t st);
+void dk_prof_end(hipStream_t st);
+
 // ---- attention -------------------------------------------------------------------------
 struct AttnParams {
   const bf16_t* Q;  // row s of batch b: Q + (b*S + s)*ld + head*D

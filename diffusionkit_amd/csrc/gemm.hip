@@ -243,10 +243,12 @@ int dk_launch_gemm(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(nbm * nbn), block(256);
+  dk_prof_begin(p.conv ? 1 : 0, 2.0 * (double)p.M * (double)p.N * (double)p.K, stream);
   if (p.conv)
     hipLaunchKernelGGL(dk_gemm_bf16_kernel<1>, grid, block, 2 * STAGE_BYTES, stream, p);
   else
     hipLaunchKernelGGL(dk_gemm_bf16_kernel<0>, grid, block, 2 * STAGE_BYTES, stream, p);
+  dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -95,6 +95,7 @@ class DiffusionPipeline:
         vae_config: Optional[VAEDecoderConfig] = None,
         weights_seed: int = 1234,
         text_len: Optional[int] = None,
+        packed_weights: Optional[dict] = None,
     ):
         _lib.load()  # fail loudly before anything else if the HIP extension is missing
         # The MI355X build computes in bf16 end to end (BASELINE.json configs); w16/a16 are
@@ -112,6 +113,7 @@ class DiffusionPipeline:
         self.vae_config = vae_config or VAEDecoderConfig()
         self.weights_seed = weights_seed
         self._text_len_override = text_len
+        self._packed_weights = packed_weights  # {"mmdit": ..., "vae_decoder": ...} already in engine layout
         self._text_encoder: Optional[Callable] = None
         self._init_sampler(shift)
         self.check_and_load_models()
@@ -126,6 +128,9 @@ class DiffusionPipeline:
         """Builds the MMDiT engine.  ``local_ckpt`` may be a dict of reference-named tensors;
         otherwise seeded synthetic weights are used (no checkpoints exist in this environment)."""
         cfg = self.mmdit_config
+        if self._packed_weights is not None and "mmdit" in self._packed_weights:
+            self.mmdit = MMDiTEngine(cfg, self._packed_weights["mmdit"])
+            return
         if isinstance(self.local_ckpt, dict) and "mmdit" in self.local_ckpt:
             named = dict(self.local_ckpt["mmdit"])
         else:
@@ -135,6 +140,8 @@ class DiffusionPipeline:
     def check_and_load_models(self):
         if not hasattr(self, "mmdit"):
             self.load_mmdit()
+        if not hasattr(self, "decoder") and self._packed_weights is not None and "vae_decoder" in self._packed_weights:
+            self.decoder = VAEDecoderEngine(self.vae_config, self._packed_weights["vae_decoder"])
         if not hasattr(self, "decoder"):
             if isinstance(self.local_ckpt, dict) and "vae_decoder" in self.local_ckpt:
                 named = self.local_ckpt["vae_decoder"]

@@ -210,6 +210,15 @@ int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int32_t latent_
                   float* image_f32, uint8_t* image_u8, void* raw_bf16, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart; the reference times phases with time.time(),
+ * mlx/__init__.py:315-530).  When enabled, every GEMM (class 0), conv (1) and attention (2) launch
+ * is bracketed by HIP events on its launch stream; dk_profile_read sums elapsed time, algorithmic
+ * FLOPs and launch count of one class since the last dk_profile_enable call.
+ * ---------------------------------------------------------------------------------------- */
+int dk_profile_enable(int32_t on);
+int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,263 @@
+"""Operator-level parity (MI355X): every C-ABI op against the CPU oracle on the same seeded,
+bf16-representable inputs.  Tolerance for one fp32-accumulated result rounded once to bf16:
+rel-L2 <= 3e-3 (tests/_util.py)."""
+import math
+
+import pytest
+import torch
+
+from oracle import mmdit as om
+from oracle import vae as ov
+from oracle.mmdit import Prec
+from tests._util import BF, TOL_SINGLE_OP, bf16r, max_abs, randn, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def g(x, dev):
+    return x.to(dev, BF).contiguous()
+
+
+# ---- GEMM ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (100, 200, 192), (1178, 1536, 1536),
+                                   (4352, 3072, 3072), (7, 64, 256), (333, 3, 1152), (2, 344 * 128, 128)])
+def test_gemm_bias(dev, M, N, K):
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=1), randn(N, K, seed=2, scale=0.05), randn(N, seed=3)
+    if N % 4:
+        out = torch.empty(M, (N + 3) // 4 * 4, dtype=BF, device=dev)
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), out=out)[:, :N]
+    else:
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev))
+    ref = x @ w.t() + b
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+    # transpose-detecting: asymmetric problem, and the worst element is within 2 bf16 ulps of the scale
+    assert max_abs(ref, y.float()) < 0.02 * float(ref.abs().max()) + 1e-2
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I, asymmetric W: catches operand / output transposes (guide rule 16)."""
+    from diffusionkit_amd import ops
+    K = 128
+    x = torch.eye(K)
+    w = bf16r(torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251 - 100)
+    y = ops.linear(g(x, dev), g(w, dev))
+    assert torch.equal(y.float().cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("epi", ["gelu", "silu", "gate_res", "res"])
+def test_gemm_epilogues(dev, epi):
+    from diffusionkit_amd import ops
+    B, S, K, N = 2, 160, 256, 384
+    M = B * S
+    x, w, b = randn(M, K, seed=4), randn(N, K, seed=5, scale=0.05), randn(N, seed=6, scale=0.1)
+    res, gate = randn(M, N, seed=7), randn(B, N, seed=8)
+    acc = bf16r(x @ w.t() + b)
+    if epi == "gelu":
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_BIAS_GELU)
+        ref = om.gelu_erf(acc, Prec())
+    elif epi == "silu":
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_BIAS_SILU)
+        ref = acc * torch.sigmoid(acc)
+    elif epi == "gate_res":
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev),
+                       gate_seg_len=S)
+        ref = res + bf16r(gate.repeat_interleave(S, 0) * acc)
+    else:
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_RES, res=g(res, dev))
+        ref = res + acc
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+
+
+def test_gemm_segment_mapping_in_place(dev):
+    """Image rows of a joint [B, S, h] buffer: A and C/res use (seg_len, seg_stride) addressing, C
+    aliases the residual (the o_proj call of post_sdpa)."""
+    from diffusionkit_amd import ops
+    B, S_t, S_i, h = 2, 24, 136, 128
+    S = S_t + S_i
+    att, X = randn(B, S, h, seed=9), randn(B, S, h, seed=10)
+    w, b, gate = randn(h, h, seed=11, scale=0.08), randn(h, seed=12, scale=0.1), randn(B, 3 * h, seed=13)
+    Xd, attd, gd = g(X, dev), g(att, dev), g(gate, dev)
+    esz = 2
+    ops.gemm_desc_call(A=attd.data_ptr() + S_t * h * esz, W=g(w, dev), C=Xd.data_ptr() + S_t * h * esz, bias=g(b, dev),
+                       gate=gd.data_ptr() + h * esz, res=Xd.data_ptr() + S_t * h * esz, M=B * S_i, N=h, K=h, lda=h, ldc=h, ldr=h,
+                       a_seg_len=S_i, a_seg_stride=S, c_seg_len=S_i, c_seg_stride=S, r_seg_len=S_i, r_seg_stride=S,
+                       gate_seg_len=S_i, gate_stride=3 * h, alpha=1.0, epilogue=ops.DK_EPI_GATE_RES)
+    ref = X.clone()
+    o = bf16r(att[:, S_t:] @ w.t() + b)
+    ref[:, S_t:] = X[:, S_t:] + bf16r(gate[:, None, h:2 * h] * o)
+    got = Xd.float().cpu()
+    assert torch.equal(got[:, :S_t], X[:, :S_t])  # text rows untouched
+    assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP
+
+
+# ---- conv ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,C,O,ups,res", [(1, 16, 16, 64, 128, False, False), (2, 8, 24, 128, 64, False, True),
+                                               (1, 16, 8, 64, 64, True, False), (1, 32, 32, 128, 3, False, False)])
+def test_conv3x3(dev, B, H, W, C, O, ups, res):
+    from diffusionkit_amd import ops
+    x = randn(B, H, W, C, seed=20)
+    w = randn(O, 3, 3, C, seed=21, scale=0.05)
+    b = randn(O, seed=22, scale=0.1)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    r = randn(B, Ho, Wo, O, seed=23) if res else None
+    y = ops.conv3x3(g(x, dev), g(w, dev), g(b, dev), upsample=ups, res=g(r, dev) if res else None)
+    xin = ov.upsample_nearest(x) if ups else x
+    ref = ov.conv2d_nhwc(xin, w, b, Prec())
+    if res:
+        ref = ref + r
+    assert y.shape == ref.shape
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+
+
+# ---- attention ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,S,D", [(1, 2, 128, 128), (1, 3, 200, 128), (2, 4, 333, 64), (1, 24, 1088, 128),
+                                     (2, 24, 589 + 64, 64)])
+def test_attention(dev, B, H, S, D):
+    from diffusionkit_amd import ops
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=30)
+    y = ops.attention(g(qkv, dev), H, D)
+    q, k, v = (qkv[..., i * h:(i + 1) * h].reshape(B, S, H, D).transpose(1, 2) for i in range(3))
+    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(B, S, h)
+    # P is rounded to bf16 before the PV product and the output once more
+    assert rel_l2(ref, y.float()) < 6e-3
+    assert max_abs(ref, y.float()) < 0.03
+
+
+def test_attention_spiked_key_forces_rescale(dev):
+    """A key that dominates late in the sequence forces the online-softmax rescale path
+    (guide rule 26); fp64 reference."""
+    from diffusionkit_amd import ops
+    B, H, S, D = 1, 1, 320, 128
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=31, scale=0.5)
+    qkv[0, 250, h:2 * h] = bf16r(qkv[0, 7, :h] * 6.0)  # key 250 aligned with query 7
+    y = ops.attention(g(qkv, dev), H, D)
+    q, k, v = (qkv[..., i * h:(i + 1) * h].double() for i in range(3))
+    p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
+    ref = (p @ v[0])[None]
+    assert rel_l2(ref, y.float()) < 6e-3
+    assert float(p[7, 250]) > 0.9
+
+
+# ---- normalisation / elementwise ------------------------------------------------------------------
+@pytest.mark.parametrize("B,S,h", [(1, 100, 256), (2, 77, 1536), (1, 300, 3072), (1, 5, 2432)])
+def test_ln_modulate(dev, B, S, h):
+    from diffusionkit_amd import ops
+    x, shift, scale = randn(B, S, h, seed=40, scale=3.0) + 0.5, randn(B, h, seed=41), randn(B, h, seed=42, scale=0.5)
+    x = bf16r(x)
+    y = ops.ln_modulate(g(x, dev), g(shift, dev), g(scale, dev))
+    P = Prec(BF)
+    ref = P.r(om.layer_norm(x, 1e-6) * P.r(1.0 + scale[:, None]) + shift[:, None])  # fused batch-1 form
+    assert rel_l2(ref, y.float()) < 2e-3
+
+
+@pytest.mark.parametrize("D,norm,rope", [(128, True, True), (64, True, False), (128, False, True)])
+def test_qk_norm_rope(dev, D, norm, rope):
+    from diffusionkit_amd import ops
+    from diffusionkit_amd.config import FLUX_SCHNELL
+    B, H, S_t, gh, gw = 2, 3, 5, 4, 6
+    S = S_t + gh * gw
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=50)
+    qw, kw = bf16r(1 + randn(D, seed=51, scale=0.1)), bf16r(1 + randn(D, seed=52, scale=0.1))
+    tab_dev = ops.rope_table(S_t, gh, gw, (16, 56, 56), 10000.0, dev) if rope else None
+    d = g(qkv, dev)
+    ops.qk_norm_rope_(d, H, D, g(qw, dev) if norm else None, g(kw, dev) if norm else None, tab_dev)
+    P = Prec(BF)
+    q, k, v = (qkv[..., i * h:(i + 1) * h].reshape(B, S, H, D).transpose(1, 2) for i in range(3))
+    if norm:
+        q, k = om.rms_norm(q, qw, 1e-6, P), om.rms_norm(k, kw, 1e-6, P)
+    if rope:
+        tab = om.rope_table(FLUX_SCHNELL, S_t, gh, gw)
+        assert max_abs(tab, tab_dev) < 2e-5  # device table vs oracle table
+        q, k = om.rope_apply(q, tab, P), om.rope_apply(k, tab, P)
+    ref = torch.cat([t.transpose(1, 2).reshape(B, S, h) for t in (q, k, v)], dim=-1)
+    got = d.float().cpu()
+    assert torch.equal(got[..., 2 * h:], qkv[..., 2 * h:])  # v untouched
+    assert rel_l2(ref, got) < 2e-3
+
+
+def test_timestep_embedding(dev):
+    from diffusionkit_amd import ops
+    from diffusionkit_amd.config import FLUX_SCHNELL, SD3_2b
+    for cfg, code, dt in ((FLUX_SCHNELL, 0, BF), (SD3_2b, 1, torch.float16)):
+        t = torch.tensor([1000.0, 752.0, 500.0, 250.0, 8.9296875, 0.0])
+        y = ops.timestep_embedding(t.to(dev), 256, 10000.0, code)
+        ref = om.timestep_embedding(t, cfg, Prec(dt))
+        # cos/sin of large bf16-rounded arguments: device and host libm may differ by 1 ulp of the
+        # low-precision output in a few entries
+        diff = (ref - y.float().cpu()).abs()
+        assert float(diff.max()) < 1.6e-2
+        assert float((diff > 1e-6).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("C,G,HW,silu", [(64, 32, (8, 8), True), (128, 32, (16, 16), False), (512, 32, (8, 8), True),
+                                         (256, 32, (32, 32), True)])
+def test_groupnorm(dev, C, G, HW, silu):
+    from diffusionkit_amd import ops
+    B = 2
+    x = bf16r(randn(B, HW[0], HW[1], C, seed=60, scale=2.0) + 0.7)
+    gamma, beta = bf16r(1 + randn(C, seed=61, scale=0.1)), randn(C, seed=62, scale=0.1)
+    y = ops.groupnorm(g(x, dev), g(gamma, dev), g(beta, dev), G, 1e-5, silu)
+    P = Prec(BF)
+    ref = ov.group_norm_nhwc(x, gamma, beta, G, 1e-5, P)
+    if silu:
+        ref = ov.silu(ref, P)
+    assert rel_l2(ref, y.float()) < 3e-3
+
+
+def test_softmax_and_transpose(dev):
+    from diffusionkit_amd import ops
+    x = randn(64, 256, seed=70, scale=3.0)
+    y = ops.softmax_rows_(g(x, dev).clone())
+    assert rel_l2(torch.softmax(x, -1), y.float()) < TOL_SINGLE_OP
+    z = ops.transpose(g(x, dev))
+    assert torch.equal(z.float().cpu(), x.t())
+
+
+@pytest.mark.parametrize("flux,cfg_on", [(True, False), (False, True), (True, True)])
+def test_patchify_and_euler_step(dev, flux, cfg_on):
+    """dk_latent_to_tokens + dk_euler_cfg_step against the oracle's patchify / unpatchify / CFG /
+    Euler restatement."""
+    from diffusionkit_amd import _lib
+    from diffusionkit_amd.config import tiny_flux, tiny_sd3
+    from diffusionkit_amd.engine import MMDiTEngine, _stream  # noqa: F401
+    from oracle.mmdit import OracleMMDiT
+    cfg = tiny_flux() if flux else tiny_sd3()
+    lib = _lib.load()
+    n_img, Hl, Wl, C, p = 2, 8, 12, 16, 2
+    x = torch.randn(n_img, Hl, Wl, C, generator=torch.Generator().manual_seed(80))
+    dup = 2 if cfg_on else 1
+    S_i, F = (Hl // p) * (Wl // p), p * p * C
+    xd = x.to(dev).contiguous()
+    tok = torch.empty(n_img * dup, S_i, F, dtype=BF, device=dev)
+    _lib.check(lib.dk_latent_to_tokens(xd.data_ptr(), tok.data_ptr(), n_img, dup, Hl, Wl, C, p, int(flux), _stream()))
+    orc = OracleMMDiT(cfg, {"x_embedder.proj.weight": torch.eye(F).reshape(F, *((1, 1, F) if flux else (p, p, C))),
+                            "x_embedder.proj.bias": torch.zeros(F)}, Prec())
+    ref_tok = orc._patch_embed(bf16r(x))  # identity projection => the patch feature order itself
+    assert torch.equal(tok.float().cpu()[:n_img], ref_tok)
+    if cfg_on:
+        assert torch.equal(tok[:n_img], tok[n_img:])
+    out = randn(n_img * dup, S_i, F, seed=81)
+    sigma, sigma_next, w = 0.75, 0.5, 5.0
+    _lib.check(lib.dk_euler_cfg_step(xd.data_ptr(), g(out, dev).data_ptr(), F, tok.data_ptr(), n_img, int(cfg_on), Hl, Wl, C, p,
+                                     int(flux), sigma, sigma_next, w, _stream()))
+    xb = bf16r(x)
+    o = orc._unpatch(out, Hl, Wl)
+    den = xb - o[:n_img] * sigma
+    if cfg_on:
+        den_neg = xb - o[n_img:] * sigma
+        den = den_neg + w * (den - den_neg)
+    ref = x + (x - den) / sigma * (sigma_next - sigma)
+    assert max_abs(ref, xd) < 1e-5
+    assert torch.equal(tok.float().cpu()[:n_img], orc._patch_embed(bf16r(xd.cpu())))
+
+
+def test_errors_do_not_cross_the_abi(dev):
+    from diffusionkit_amd import _lib, ops
+    with pytest.raises(_lib.DkHipError, match="multiple of 64"):
+        ops.linear(g(randn(8, 40), dev), g(randn(8, 40), dev))
+    with pytest.raises(_lib.DkHipError, match="head_dim"):
+        ops.attention(g(randn(1, 8, 3 * 96), dev), 1, 96)
