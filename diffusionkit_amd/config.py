@@ -60,6 +60,16 @@ class MMDiTConfig:
     def is_flux(self) -> bool:
         return self.depth_unified > 0
 
+    def param_count(self) -> int:
+        """Approximate parameter count (linear weights only): 12 h^2 per stream / single block plus
+        the adaLN Linears."""
+        h = self.hidden_size
+        per_stream = (4 + 2 * self.mlp_ratio) * h * h
+        n = (2 * self.depth_multimodal + self.depth_unified) * per_stream
+        n += self.num_modulation_rows() * h * h
+        n += (self.token_level_text_embed_dim + self.pooled_text_embed_dim + self.frequency_embed_dim + 2 * h) * h
+        return n
+
     def num_modulation_rows(self) -> int:
         """Number of hidden-size rows of adaLN output per (timestep, batch row).
 

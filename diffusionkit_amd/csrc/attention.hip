@@ -32,7 +32,7 @@ template <int D>
 __device__ __forceinline__ int k_swz(int r) { return D == 128 ? (r & 15) : ((r >> 1) & 7); }
 
 template <int D>
-__global__ __launch_bounds__(256) void dk_attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
   using C = AttnCfg<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                       // [2][TILE_BYTES]

@@ -12,11 +12,11 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __restrict__ x, long HW, int C, int G, float* __restrict__ partial,
                                                             int nchunk) {
-  __shared__ float gs[2 * 64];
+  // per-thread (sum, sumsq) of 8 channels, combined in a FIXED order (no atomics: the statistics,
+  // and with them the decoded image, must be bit-reproducible for a fixed seed)
+  __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  if (tid < 2 * G) gs[tid] = 0.f;
-  __syncthreads();
   const int tpp = C / 8;           // threads per pixel
   const int ppi = 256 / tpp;       // pixels per iteration
   const int cg = tid % tpp;        // channel chunk of this thread
@@ -26,28 +26,31 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  if (pl < ppi) {
-    const bf16_t* base = x + (size_t)b * HW * C + cg * 8;
-    for (long pix = p0 + pl; pix < p1; pix += ppi) {
-      const u32x4 raw = *(const u32x4*)(base + (size_t)pix * C);
+  const bf16_t* base = x + (size_t)b * HW * C + cg * 8;
+  for (long pix = p0 + pl; pix < p1; pix += ppi) {
+    const u32x4 raw = *(const u32x4*)(base + (size_t)pix * C);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a0, a1;
-        unpack2bf(raw[e], a0, a1);
-        s[2 * e] += a0; q[2 * e] += a0 * a0;
-        s[2 * e + 1] += a1; q[2 * e + 1] += a1 * a1;
-      }
-    }
-    const int cpg = C / G;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int g = (cg * 8 + e) / cpg;
-      atomicAdd(&gs[2 * g], s[e]);
-      atomicAdd(&gs[2 * g + 1], q[e]);
+    for (int e = 0; e < 4; ++e) {
+      float a0, a1;
+      unpack2bf(raw[e], a0, a1);
+      s[2 * e] += a0; q[2 * e] += a0 * a0;
+      s[2 * e + 1] += a1; q[2 * e + 1] += a1 * a1;
     }
   }
+  // red[stat][pl][channel]: channel = cg*8 + e
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(0 * ppi + pl) * C + cg * 8 + e] = s[e];
+    red[(1 * ppi + pl) * C + cg * 8 + e] = q[e];
+  }
   __syncthreads();
-  if (tid < 2 * G) partial[((size_t)b * nchunk + chunk) * 2 * G + tid] = gs[tid];
+  if (tid < 2 * G) {
+    const int g = tid >> 1, stat = tid & 1, cpg = C / G;
+    float acc = 0.f;
+    for (int pp = 0; pp < ppi; ++pp)
+      for (int c = 0; c < cpg; ++c) acc += red[(stat * ppi + pp) * C + g * cpg + c];
+    partial[((size_t)b * nchunk + chunk) * 2 * G + tid] = acc;
+  }
 }
 __global__ void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
                                       float* __restrict__ mean_rstd) {

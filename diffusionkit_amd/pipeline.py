@@ -134,8 +134,14 @@ class DiffusionPipeline:
         if isinstance(self.local_ckpt, dict) and "mmdit" in self.local_ckpt:
             named = dict(self.local_ckpt["mmdit"])
         else:
-            named = synth_mmdit_weights(cfg, seed=self.weights_seed, device=self.device)
+            named = synth_mmdit_weights(cfg, seed=self.weights_seed, device=self._synth_device(cfg.param_count()))
         self.mmdit = MMDiTEngine(cfg, pack_mmdit(cfg, named, self.device, consume=True))
+
+    def _synth_device(self, n_params: int):
+        """Seeded synthetic weights come from the CPU generator stream (the one the oracle and the
+        parity tests draw from) unless the model is too large to draw on the host in reasonable time;
+        above 1e9 parameters the device generator is used (a different, equally seeded stream)."""
+        return "cpu" if n_params < 1_000_000_000 else self.device
 
     def check_and_load_models(self):
         if not hasattr(self, "mmdit"):
@@ -146,7 +152,7 @@ class DiffusionPipeline:
             if isinstance(self.local_ckpt, dict) and "vae_decoder" in self.local_ckpt:
                 named = self.local_ckpt["vae_decoder"]
             else:
-                named = synth_vae_weights(self.vae_config, seed=self.weights_seed + 1, device=self.device)
+                named = synth_vae_weights(self.vae_config, seed=self.weights_seed + 1, device="cpu")
             self.decoder = VAEDecoderEngine(self.vae_config, pack_vae(self.vae_config, named, self.device))
 
     # -- text conditioning (outside the hot path) ------------------------------------------------
