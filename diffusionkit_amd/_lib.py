@@ -28,7 +28,8 @@ class dk_gemm_desc(C.Structure):
         ("c_seg_len", C.c_int32), ("c_seg_stride", C.c_int32),
         ("r_seg_len", C.c_int32), ("r_seg_stride", C.c_int32),
         ("gate_seg_len", C.c_int32), ("gate_stride", C.c_int32),
-        ("alpha", C.c_float), ("epilogue", C.c_int32),
+        ("alpha", C.c_float), ("epilogue", C.c_int32), ("ldw", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "dk_abi_version": (_i32, []),
     "dk_last_error": (C.c_char_p, []),
     "dk_gemm_bf16": (_i32, [C.POINTER(dk_gemm_desc), _vp]),
+    "dk_gemm_workspace_bytes": (C.c_size_t, []),
     "dk_conv3x3_bf16": (_i32, [C.POINTER(dk_conv_desc), _vp]),
     "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dk_ln_modulate_bf16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
@@ -103,6 +105,7 @@ SIGNATURES = {
     "dk_vae_decode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dk_profile_enable": (_i32, [_i32]),
     "dk_profile_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dk_tune_set": (_i32, [C.c_char_p, _i32]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -18,6 +18,7 @@ struct GemmParams {
   const bf16_t* res;   // same row mapping as C, leading dim ldr
   int M, N, K;
   int lda, ldc, ldr;
+  int ldw;  // row stride of W in elements (>= K; a padded stride avoids L2-channel camping on power-of-two K)
   int a_seg_len, a_seg_stride;
   int c_seg_len, c_seg_stride;
   int r_seg_len, r_seg_stride;
@@ -30,8 +31,16 @@ struct GemmParams {
   int conv;
   int cB, cH, cW, cC, ups;
   const bf16_t* zeros;  // >= 128 B of zeros (padding taps)
+  void* workspace;      // optional stream-K workspace (dk_streamk_workspace_bytes()), else null
+  size_t workspace_bytes;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
+int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream);  // gemm256.hip
+extern int g_dk_gemm_mode;
+// stream-K form (persistent grid, fp32 slabs + flags in a caller-owned workspace whose last 4 KiB
+// -- the flag region -- must be zero before the first launch; kernels leave it zero)
+size_t dk_streamk_workspace_bytes();
+int dk_launch_gemm256_streamk(const GemmParams& p, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention
 void dk_prof_begin(int cls, double work, hipStream_t st);

@@ -18,6 +18,15 @@ void dk_set_error(const std::string& msg) { g_last_error = msg; }
 extern "C" int dk_abi_version(void) { return DK_ABI_VERSION; }
 extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
 
+int g_dk_attn_mode = -1;
+extern "C" int dk_tune_set(const char* key, int32_t value) {
+  DK_REQUIRE(key != nullptr, "null key");
+  if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
+  if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
+  dk_set_error(std::string("unknown tuning key: ") + key);
+  return -1;
+}
+
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -35,9 +44,12 @@ static GemmParams gemm_params_from_desc(const dk_gemm_desc* d) {
   p.c_seg_len = d->c_seg_len > 0 ? d->c_seg_len : d->M; p.c_seg_stride = d->c_seg_stride;
   p.r_seg_len = d->r_seg_len > 0 ? d->r_seg_len : d->M; p.r_seg_stride = d->r_seg_stride;
   p.gate_seg_len = d->gate_seg_len > 0 ? d->gate_seg_len : d->M; p.gate_stride = d->gate_stride;
-  p.alpha = d->alpha; p.epi = d->epilogue;
+  p.alpha = d->alpha; p.epi = d->epilogue; p.ldw = d->ldw;
+  p.workspace = d->workspace; p.workspace_bytes = d->workspace_bytes;
   return p;
 }
+
+extern "C" size_t dk_gemm_workspace_bytes(void) { return dk_streamk_workspace_bytes(); }
 
 extern "C" int dk_gemm_bf16(const dk_gemm_desc* d, void* stream) {
   DK_REQUIRE(d != nullptr, "null descriptor");

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
     const int r = wave * 32 + i * 8 + srow;  // tile-local row
     const int chunk = (lane & 7) ^ ((r >> 1) & 7);
     int n = min(n0 + r, p.N - 1);
-    w_src[i] = p.W + (size_t)n * p.K + chunk * 8;
+    w_src[i] = p.W + (size_t)n * p.ldw + chunk * 8;
     int m = min(m0 + r, p.M - 1);
     if (AMODE == 0) {
       const int phys = (m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len);
@@ -223,8 +223,34 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-int dk_launch_gemm(const GemmParams& p, hipStream_t stream) {
+// tuning knob (dk_tune_set("gemm", v)): -1 = automatic choice, 128 = always the 128^2 kernel,
+// 0 / 1 = always the 256^2 kernel with that schedule variant (when the shape allows it)
+int g_dk_gemm_mode = -1;
+
+// Kernel choice from the kernel-lab measurements (profiles/r01_gemm_lab.md): the 256^2 kernel has the
+// better per-CU rate (fewer L2->LDS bytes per FLOP) but one workgroup per CU, so it pays when its
+// tiles fill the 256 CUs well: a single wave of >= 60 % of the CUs, or several waves at >= 78 %.
+static bool prefer_256(const GemmParams& p) {
+  if (p.conv || p.N % 256 != 0 || p.M < 1024) return false;
+  const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+  const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+  return t256 <= 256 ? eff256 >= 0.60 : eff256 >= 0.78;
+}
+
+int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  if (p.ldw <= 0) p.ldw = p.K;
   DK_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
+  DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
+  if (!p.conv && g_dk_gemm_mode != 128 && p.N % 4 == 0 && p.K % 64 == 0 && p.lda % 8 == 0) {
+    const bool sk_ok = p.workspace != nullptr && p.N % 256 == 0 && p.M >= 1024;
+    if (g_dk_gemm_mode == 3) {
+      DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
+      return dk_launch_gemm256_streamk(p, p.workspace, p.workspace_bytes, stream);
+    }
+    if (g_dk_gemm_mode >= 0 && g_dk_gemm_mode < 128) return dk_launch_gemm256(p, g_dk_gemm_mode, stream);
+    if (prefer_256(p)) return dk_launch_gemm256(p, 5, stream);
+  }
   DK_REQUIRE(p.K % BK == 0, "K must be a multiple of 64");
   DK_REQUIRE(p.ldc % 4 == 0, "ldc must be a multiple of 4 elements");
   DK_REQUIRE(p.conv || (p.lda % 8 == 0), "lda must be a multiple of 8 elements");

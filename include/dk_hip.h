@@ -65,7 +65,15 @@ typedef struct dk_gemm_desc {
   int32_t gate_stride;
   float alpha;          /* scales the accumulator before the bias (1.0 for Linear) */
   int32_t epilogue;
+  int32_t ldw;          /* row stride of W in elements; 0 = K (contiguous nn.Linear weight) */
+  /* Optional scratch for the stream-K kernel (large M, N % 256 == 0): dk_gemm_workspace_bytes()
+   * bytes, 256-byte aligned, whose LAST 4096 bytes are zero before the first use (the kernels leave
+   * them zero).  NULL = tile-parallel kernels only.  One GEMM at a time may use a given workspace. */
+  void* workspace;
+  size_t workspace_bytes;
 } dk_gemm_desc;
+
+size_t dk_gemm_workspace_bytes(void);
 
 /* nn.Linear call sites of the hot path: mmdit.py:56,358-360,373-375,432,771,777,821-832;
  * vae.py:36-39,84 */
@@ -218,6 +226,12 @@ int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int32_t latent_
  * ---------------------------------------------------------------------------------------- */
 int dk_profile_enable(int32_t on);
 int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops, int64_t* launches);
+
+/* Tuning knobs for A/B measurements (no reference counterpart).  key "gemm": -1 automatic kernel
+ * choice (default), 128 = 128x128 tiles only, 0 / 1 / 2 = 256x256 tiles (simple / staggered / spread-DMA
+ * schedule), 3 = 256x256 stream-K (needs the descriptor's workspace).  key "attn": kernel variant of dk_attention_bf16 (-1 automatic).  Returns 0, or -1 for an
+ * unknown key. */
+int dk_tune_set(const char* key, int32_t value);
 
 #ifdef __cplusplus
 }
