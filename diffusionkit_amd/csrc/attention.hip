@@ -19,21 +19,27 @@
 // which accumulates O^T = V^T P^T (query again per lane => rescaling by alpha is lane-local).
 #include "dk_kernels.h"
 
-template <int D>
+template <int D, int NW = 4>
 struct AttnCfg {
-  static constexpr int KV = 64;                    // keys per tile
-  static constexpr int ROWB = D * 2;               // bytes per K row
-  static constexpr int TILE_BYTES = KV * D * 2;    // one K (or V) tile
-  static constexpr int NCH = KV * D / 8 / 256;     // 16-byte chunks per thread per tile
-  static constexpr int CPR = D / 8;                // chunks per row
+  static constexpr int KV = 64;                          // keys per tile
+  static constexpr int ROWB = D * 2;                     // bytes per K row
+  static constexpr int TILE_BYTES = KV * D * 2;          // one K (or V) tile
+  static constexpr int NT = NW * 64;                     // threads per workgroup
+  static constexpr int NCH = KV * D / 8 / NT;            // 16-byte chunks per thread per tile
+  static constexpr int CPR = D / 8;                      // chunks per row
+  static constexpr int QB = NW * 32;                     // query rows per workgroup
 };
 
 template <int D>
 __device__ __forceinline__ int k_swz(int r) { return D == 128 ? (r & 15) : ((r >> 1) & 7); }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
-  using C = AttnCfg<D>;
+// NW = waves per workgroup (4: 128 query rows, two workgroups per CU; 8: 256 query rows, K/V staging
+// shared by twice as many waves).  VAR bit 0: the two 32-key score chains of a tile are interleaved
+// (two independent accumulator chains instead of 8 dependent MFMAs in a row) and the MFMA clusters run
+// at raised priority.
+template <int D, int NW, int VAR>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void dk_attn_fwd_kernel(AttnParams p) {
+  using C = AttnCfg<D, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                       // [2][TILE_BYTES]
   char* Vs = smem + 2 * C::TILE_BYTES;   // [2][TILE_BYTES]
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
   const int S = p.S;
 
   // XCD-contiguous block order so that the blocks of one head share an L2.
-  const int nq = (S + 127) / 128;
+  const int nq = (S + C::QB - 1) / C::QB;
   int t;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int qb = t % nq, head = (t / nq) % p.H, b = t / (nq * p.H);
-  const int q0 = qb * 128 + wave * 32;
+  const int q0 = qb * C::QB + wave * 32;
 
   const bf16_t* Qb = p.Q + (size_t)b * S * p.ld + head * D;
   const bf16_t* Kb = p.K + (size_t)b * S * p.ld + head * D;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
   int st_kl[C::NCH], st_c8[C::NCH];
 #pragma unroll
   for (int i = 0; i < C::NCH; ++i) {
-    const int id = tid + 256 * i;
+    const int id = tid + C::NT * i;
     st_kl[i] = id / C::CPR;
     st_c8[i] = id % C::CPR;
   }
@@ -113,14 +119,30 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
     // ---- S^T[key, q] for the 64 keys of this tile (2 sub-tiles of 32 keys) ----
     f32x16 s[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
-      const int r = u * 32 + l31;
+    if (VAR & 1) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < D / 16; ++kk) {
-        const bf16x8 kf = *(const bf16x8*)(Kt + r * C::ROWB + (((kk * 2 + hi) ^ k_swz<D>(r)) << 4));
-        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = u * 32 + l31;
+          const bf16x8 kf = *(const bf16x8*)(Kt + r * C::ROWB + (((kk * 2 + hi) ^ k_swz<D>(r)) << 4));
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[u], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = u * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) {
+          const bf16x8 kf = *(const bf16x8*)(Kt + r * C::ROWB + (((kk * 2 + hi) ^ k_swz<D>(r)) << 4));
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[u], 0, 0, 0);
+        }
       }
     }
     // tail tile: keys beyond S do not exist
@@ -160,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
       for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
 
     // ---- O^T += V^T P^T ----
+    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -185,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
       }
     }
 
+    if (VAR & 1) __builtin_amdgcn_s_setprio(0);
     if (j + 1 < ntiles) { DK_STORE_TILE(buf ^ 1) }
     __syncthreads();
   }
@@ -207,24 +231,46 @@ __global__ __launch_bounds__(256, 2) void dk_attn_fwd_kernel(AttnParams p) {
   }
 }
 
+extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 0 = 4 waves; 1 = 4 waves interleaved; 2 / 3 = 8 waves
+
+template <int D, int NW, int VAR>
+static int launch_attn(const AttnParams& p, hipStream_t stream) {
+  using C = AttnCfg<D, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn_fwd_kernel<D, NW, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::TILE_BYTES));
+    attr_set = true;
+  }
+  const int nq = (p.S + C::QB - 1) / C::QB;
+  hipLaunchKernelGGL((dk_attn_fwd_kernel<D, NW, VAR>), dim3(nq * p.H * p.B), dim3(C::NT), 4 * C::TILE_BYTES, stream, p);
+  return 0;
+}
+
 int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
   DK_REQUIRE(p.D == 128 || p.D == 64, "head_dim must be 64 or 128");
   DK_REQUIRE(p.S > 0 && p.B > 0 && p.H > 0, "empty attention");
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");
-  const int nq = (p.S + 127) / 128;
-  dim3 grid(nq * p.H * p.B), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AttnCfg<128>::TILE_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AttnCfg<64>::TILE_BYTES));
-    attr_set = true;
-  }
+  // automatic choice (kernel lab, profiles/r01_attention_lab.md): the VALU-lean kernel, 8 waves per
+  // workgroup for D = 128 on long sequences (K/V staging shared by 8 waves), 4 waves otherwise
+  const int mode = g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 5 : 4) : g_dk_attn_mode;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
-  if (p.D == 128)
-    hipLaunchKernelGGL(dk_attn_fwd_kernel<128>, grid, block, 4 * AttnCfg<128>::TILE_BYTES, stream, p);
-  else
-    hipLaunchKernelGGL(dk_attn_fwd_kernel<64>, grid, block, 4 * AttnCfg<64>::TILE_BYTES, stream, p);
+  int rc = 0;
+#define DK_ATTN_CASE(M, NW, VAR)                                                     \
+  case M:                                                                           \
+    rc = p.D == 128 ? launch_attn<128, NW, VAR>(p, stream) : launch_attn<64, NW, VAR>(p, stream); \
+    break;
+  switch (mode) {
+    DK_ATTN_CASE(0, 4, 0)
+    DK_ATTN_CASE(1, 4, 1)
+    DK_ATTN_CASE(2, 8, 0)
+    DK_ATTN_CASE(3, 8, 1)
+    case 4: rc = dk_launch_attention2(p, 4, stream); break;
+    case 5: rc = dk_launch_attention2(p, 8, stream); break;
+    default: DK_REQUIRE(false, "unknown attention variant");
+  }
+#undef DK_ATTN_CASE
   dk_prof_end(stream);
+  if (rc) return rc;
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }

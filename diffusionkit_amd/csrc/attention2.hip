@@ -1,0 +1,245 @@
+// Joint text/image attention forward, VALU-lean variant (dk_attn2_fwd_kernel).
+//
+// Same algorithm, layouts and MFMA operand mapping as dk_attn_fwd_kernel (attention.hip; reference
+// call sites python/src/diffusionkit/mlx/mmdit.py:562,643,687,736) -- transposed scores S^T = K Q^T,
+// lane-local online softmax, O^T += V^T P^T with V read through ds_read_b64_tr_b16 -- but the per-tile
+// instruction stream is cut down, because rocprofv3 counters showed the first kernel VALU-bound
+// (13 VALU per MFMA, VALU busy 59 %, MFMA busy 33 %; profiles/r01_attention_pmc.md):
+//   * K/V tile loads use ONE 32-bit lane offset per 16-byte chunk against a wave-uniform base that
+//     advances per tile (global_load saddr form): no per-tile address arithmetic, the key clamp is
+//     evaluated only in the tail tile;
+//   * every LDS offset (swizzled K fragments, V transpose-read base, staging stores) is computed
+//     once per kernel; the tile body only adds compile-time immediates (the loop is unrolled over
+//     the two LDS buffers for that);
+//   * the running-max rescale of O (64 multiplies) runs only when some query of the wave raised its
+//     maximum by more than DK_RESCALE_THR (wave-uniform vote); probabilities are then bounded by
+//     e^THR instead of 1, which fp32 accumulation and bf16 P tolerate (guide T13; the safe order is
+//     kept: the decision precedes the exponentials of the tile it covers, nothing else is pending);
+//   * the two 32-key score chains of a tile are interleaved (two independent accumulators).
+#include "dk_kernels.h"
+
+#define DK_RESCALE_THR 4.0f  // natural-log units of the scaled scores
+
+template <int D, int NW>
+struct Attn2Cfg {
+  static constexpr int KV = 64;
+  static constexpr int ROWB = D * 2;
+  static constexpr int TILE_BYTES = KV * D * 2;
+  static constexpr int NT = NW * 64;
+  static constexpr int NCH = KV * D / 8 / NT;
+  static constexpr int CPR = D / 8;
+  static constexpr int QB = NW * 32;
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2] V[2]
+};
+
+template <int D>
+__device__ __forceinline__ int k2_swz(int r) { return D == 128 ? (r & 15) : ((r >> 1) & 7); }
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) {
+  using C = Attn2Cfg<D, NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // The dynamic LDS region starts at LDS address 0 (this kernel has no static __shared__ objects), so
+  // LDS accesses are formed from small integer addresses: hipcc then knows the address bits and
+  // folds every compile-time offset into the ds instruction's immediate field instead of emitting a
+  // v_add per access (it cannot prove base + offset stays non-negative for a symbol address).
+  if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();
+  lds_char* const lds = (lds_char*)0;
+  constexpr int K_OFF = 0, V_OFF = 2 * C::TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int S = p.S;
+
+  const int nq = (S + C::QB - 1) / C::QB;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int qb = t % nq, head = (t / nq) % p.H, b = t / (nq * p.H);
+  const int q0 = qb * C::QB + wave * 32;
+
+  const bf16_t* Qb = p.Q + (size_t)b * S * p.ld + head * D;
+  const char* Kb = (const char*)(p.K + (size_t)b * S * p.ld + head * D);  // wave-uniform bases
+  const char* Vb = (const char*)(p.V + (size_t)b * S * p.ld + head * D);
+  const unsigned row_bytes = (unsigned)p.ld * 2u;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][kk*16 + hi*8 .. +7]
+  bf16x8 qf[D / 16];
+  {
+    const int qrow = min(q0 + l31, S - 1);
+    const bf16_t* qp = Qb + (size_t)qrow * p.ld + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+  }
+
+  // ---- per-thread constants: staging chunk coordinates, global lane offsets, LDS offsets ----
+  unsigned g_off[C::NCH];   // byte offset of chunk i inside a 64-key tile (key-local row, 16-byte column)
+  unsigned ks_off[C::NCH];  // LDS store offset inside a K tile
+  unsigned vs_off[C::NCH];  // LDS store offset inside a V tile
+  int st_kl[C::NCH];
+#pragma unroll
+  for (int i = 0; i < C::NCH; ++i) {
+    const int id = tid + C::NT * i;
+    const int kl = id / C::CPR, c8 = id % C::CPR;
+    st_kl[i] = kl;
+    g_off[i] = (unsigned)kl * row_bytes + (unsigned)c8 * 16u;
+    ks_off[i] = (unsigned)(kl * C::ROWB + ((c8 ^ k2_swz<D>(kl)) << 4));
+    // V image: [d/16][key][16]; odd d-blocks store key rows with bit 2 flipped (tr-read bank halves)
+    vs_off[i] = (unsigned)((c8 >> 1) * 2048 + (kl ^ (((c8 >> 1) & 1) << 2)) * 32 + (c8 & 1) * 16);
+  }
+  unsigned kr_off[D / 16];  // K fragment read: row l31 (+32 per sub-tile as an immediate), swizzled chunk
+#pragma unroll
+  for (int kk = 0; kk < D / 16; ++kk) kr_off[kk] = (unsigned)(l31 * C::ROWB + (((kk * 2 + hi) ^ k2_swz<D>(l31)) << 4));
+  const int x16 = (lane >> 4) & 1, p16 = lane & 15;
+  const unsigned vr_off = (unsigned)(x16 * 2048 + (4 * (hi ^ x16) + (p16 >> 2)) * 32 + (p16 & 3) * 8);
+
+  u32x4 kreg[C::NCH], vreg[C::NCH];
+  const int ntiles = (S + 63) / 64;
+  auto load_tile = [&](int j) {
+    const char* kb = Kb + (size_t)j * 64 * row_bytes;
+    const char* vb = Vb + (size_t)j * 64 * row_bytes;
+    if (j * 64 + 64 <= S) {
+#pragma unroll
+      for (int i = 0; i < C::NCH; ++i) {
+        kreg[i] = *(const u32x4*)(kb + g_off[i]);
+        vreg[i] = *(const u32x4*)(vb + g_off[i]);
+      }
+    } else {  // tail tile: rows beyond S - 1 re-read the last key (their scores are masked below)
+#pragma unroll
+      for (int i = 0; i < C::NCH; ++i) {
+        const int kl = min(st_kl[i], S - 1 - j * 64);
+        const unsigned off = (unsigned)kl * row_bytes + (g_off[i] - (unsigned)st_kl[i] * row_bytes);
+        kreg[i] = *(const u32x4*)(kb + off);
+        vreg[i] = *(const u32x4*)(vb + off);
+      }
+    }
+  };
+#define DK2_STORE_TILE(BUF)                                                            \
+  _Pragma("unroll") for (int i = 0; i < C::NCH; ++i) {                                 \
+    *(__attribute__((address_space(3))) u32x4*)(lds + K_OFF + (BUF) * C::TILE_BYTES + ks_off[i]) = kreg[i]; \
+    *(__attribute__((address_space(3))) u32x4*)(lds + V_OFF + (BUF) * C::TILE_BYTES + vs_off[i]) = vreg[i]; \
+  }
+
+  f32x16 o[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale * 1.44269504088896340736f;  // p = 2^(s*c - m*c)
+  const float thr = DK_RESCALE_THR / p.scale;          // threshold on the raw scores
+
+  load_tile(0);
+  DK2_STORE_TILE(0)
+  __syncthreads();
+
+#define DK2_TILE(BUF, J)                                                                                   \
+  do {                                                                                                     \
+    const int j_ = (J);                                                                                    \
+    if (j_ + 1 < ntiles) load_tile(j_ + 1);                                                                \
+    f32x16 s0, s1;                                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }                           \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < D / 16; ++kk) {                                                \
+      const bf16x8 k0 = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (BUF) * C::TILE_BYTES + kr_off[kk]); \
+      const bf16x8 k1 = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (BUF) * C::TILE_BYTES + 32 * C::ROWB + kr_off[kk]); \
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], s0, 0, 0, 0);                               \
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], s1, 0, 0, 0);                               \
+    }                                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    if (j_ * 64 + 64 > S) {                                                                                \
+      asm volatile("; tail tile" ::: "memory"); /* keeps hipcc from if-converting the mask into every tile */ \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                     \
+        const int key = j_ * 64 + (e & 3) + 8 * (e >> 2) + 4 * hi;                                         \
+        if (key >= S) s0[e] = -1e30f;                                                                      \
+        if (key + 32 >= S) s1[e] = -1e30f;                                                                 \
+      }                                                                                                    \
+    }                                                                                                      \
+    float mloc = fmaxf(s0[0], s1[0]);                                                                      \
+    _Pragma("unroll") for (int e = 1; e < 16; ++e) mloc = fmaxf(mloc, fmaxf(s0[e], s1[e]));                \
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));                                                          \
+    if (!__all(mloc - m_run <= thr)) {                                                                     \
+      const float m_new = fmaxf(m_run, mloc);                                                              \
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                     \
+      m_run = m_new;                                                                                       \
+      l_run *= alpha;                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < D / 32; ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) o[i][e] *= alpha; \
+    }                                                                                                      \
+    const float mc = m_run * c;                                                                            \
+    float psum = 0.f;                                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
+      s0[e] = __builtin_amdgcn_exp2f(s0[e] * c - mc);                                                      \
+      s1[e] = __builtin_amdgcn_exp2f(s1[e] * c - mc);                                                      \
+      psum += s0[e] + s1[e];                                                                               \
+    }                                                                                                      \
+    l_run += psum;                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                        \
+      _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                   \
+        bf16x8 pf;                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) pf[e] = (__bf16)(u == 0 ? s0[8 * tt + e] : s1[8 * tt + e]); \
+        _Pragma("unroll") for (int dt = 0; dt < D / 32; ++dt) {                                            \
+          const int imm = V_OFF + (BUF) * C::TILE_BYTES + dt * 4096 + (32 * u + 16 * tt) * 32;             \
+          const s16x4 vh0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + vr_off)); \
+          const s16x4 vh1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + 256 + vr_off)); \
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7)); \
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);                         \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+    if (j_ + 1 < ntiles) { DK2_STORE_TILE((BUF) ^ 1) }                                                     \
+    __syncthreads();                                                                                       \
+  } while (0)
+
+  int j = 0;
+  for (; j + 1 < ntiles; j += 2) {
+    DK2_TILE(0, j);
+    DK2_TILE(1, j + 1);
+  }
+  if (j < ntiles) DK2_TILE(0, j);
+#undef DK2_TILE
+#undef DK2_STORE_TILE
+
+  // ---- normalise and store: lane owns query q0+l31, d = dt*32 + 8g + 4hi + {0..3} ----
+  const float lsum = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / lsum;
+  const int q = q0 + l31;
+  if (q < S) {
+    bf16_t* op = p.O + ((size_t)b * S + q) * p.ldo + head * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 w;
+        w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+        w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+        *(uint2*)(op + dt * 32 + 8 * g4 + 4 * hi) = w;
+      }
+  }
+}
+
+template <int D, int NW>
+static int launch_attn2(const AttnParams& p, hipStream_t stream) {
+  using C = Attn2Cfg<D, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  const int nq = (p.S + C::QB - 1) / C::QB;
+  hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
+  return 0;
+}
+
+int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
+  DK_REQUIRE((size_t)p.S * p.ld * 2 < (1ull << 32), "attention2: one batch row of QKV must span < 4 GiB");
+  if (p.D == 128) return waves == 8 ? launch_attn2<128, 8>(p, stream) : launch_attn2<128, 4>(p, stream);
+  return waves == 8 ? launch_attn2<64, 8>(p, stream) : launch_attn2<64, 4>(p, stream);
+}

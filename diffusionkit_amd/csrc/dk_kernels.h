@@ -57,6 +57,7 @@ struct AttnParams {
   float scale;
 };
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
+int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 
 // ---- elementwise / normalisation ---------------------------------------------------------
 // out[m, :] = bf16( LN(x[m, :]) * bf16(1 + scale[b, :]) + shift[b, :] ), b = m / seg_len

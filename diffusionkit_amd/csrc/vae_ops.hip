@@ -52,20 +52,27 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
     partial[((size_t)b * nchunk + chunk) * 2 * G + tid] = acc;
   }
 }
-__global__ void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
-                                      float* __restrict__ mean_rstd) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
+// one wave per (batch, group): lanes stride over the chunk partials, fixed-order shuffle tree (double)
+__global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
+                                                            float* __restrict__ mean_rstd) {
+  const int b = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = lane; c < nchunk; c += 64) {
     s += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g];
     q += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g + 1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
-  mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
+    mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, float* mean_rstd,
                               float eps, hipStream_t stream) {
@@ -74,7 +81,7 @@ int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, flo
   DK_REQUIRE(nchunk >= 1, "nchunk");
   hipLaunchKernelGGL(dk_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, HW, C, G, partial, nchunk);
   DK_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B), dim3(64), 0, stream, partial, nchunk, G,
+  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B * G), dim3(64), 0, stream, partial, nchunk, G,
                      (double)HW * (double)(C / G), eps, mean_rstd);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -3,9 +3,10 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_lab/obj
-for f in gemm gemm256 attention elementwise vae_ops profile engine; do
+for f in gemm gemm256 attention attention2 elementwise vae_ops profile engine; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDK_LAB_ABLATIONS -c diffusionkit_amd/csrc/$f.hip -o build_lab/obj/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_lab/libdk_hip.so build_lab/obj/*.o
 /opt/rocm/bin/hipcc -O2 -std=c++17 -w scripts/gemm_lab.cpp -Iinclude -Lbuild_lab -ldk_hip -Wl,-rpath,'$ORIGIN' -o build_lab/gemm_lab
+/opt/rocm/bin/hipcc -O2 -std=c++17 -w scripts/attn_lab.cpp -Iinclude -Lbuild_lab -ldk_hip -Wl,-rpath,'$ORIGIN' -o build_lab/attn_lab
