@@ -40,7 +40,8 @@ extern int g_dk_gemm_mode;
 // stream-K form (persistent grid, fp32 slabs + flags in a caller-owned workspace whose last 4 KiB
 // -- the flag region -- must be zero before the first launch; kernels leave it zero)
 size_t dk_streamk_workspace_bytes();
-int dk_launch_gemm256_streamk(const GemmParams& p, void* workspace, size_t workspace_bytes, hipStream_t stream);
+bool dk_gemm256v2_eligible(const GemmParams& p);
+int dk_launch_gemm256v2(const GemmParams& p, bool streamk, hipStream_t stream);  // gemm256sk.hip
 
 // optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention
 void dk_prof_begin(int cls, double work, hipStream_t st);

@@ -243,12 +243,20 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   DK_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
   if (!p.conv && g_dk_gemm_mode != 128 && p.N % 4 == 0 && p.K % 64 == 0 && p.lda % 8 == 0) {
-    const bool sk_ok = p.workspace != nullptr && p.N % 256 == 0 && p.M >= 1024;
+    const bool v2_ok = dk_gemm256v2_eligible(p);
+    const bool sk_ok = v2_ok && p.workspace != nullptr && p.M >= 1024;
     if (g_dk_gemm_mode == 3) {
       DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
-      return dk_launch_gemm256_streamk(p, p.workspace, p.workspace_bytes, stream);
+      return dk_launch_gemm256v2(p, true, stream);
+    }
+    if (g_dk_gemm_mode == 6) {
+      DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
+      return dk_launch_gemm256v2(p, false, stream);
     }
     if (g_dk_gemm_mode >= 0 && g_dk_gemm_mode < 128) return dk_launch_gemm256(p, g_dk_gemm_mode, stream);
+    // automatic choice (kernel lab, profiles/r01_gemm_lab_v2.log): the second-generation 256^2 kernel wins
+    // on every eligible large-M shape; ineligible shapes fall back to the first 256^2 kernel / 128^2 tiles
+    if (v2_ok && p.M >= 1024) return dk_launch_gemm256v2(p, false, stream);
     if (prefer_256(p)) return dk_launch_gemm256(p, 5, stream);
   }
   DK_REQUIRE(p.K % BK == 0, "K must be a multiple of 64");

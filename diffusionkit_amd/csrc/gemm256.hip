@@ -456,269 +456,6 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256_bf16_kernel(GemmParams p) {
   dk_epilogue256(p, acc, m0, n0, wm, wn, hi, l31);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stream-K form of the same tile: a persistent grid of G workgroups (one per CU) splits the
-// T * nk K-tile iterations of the whole problem evenly, so a GEMM whose tile count is not a multiple
-// of the CU count (N = 3072 linears: 192 / 204 tiles on 256 CUs; qkv: 2.25 waves) still keeps
-// every CU busy to the end.  A workgroup walks its contiguous iteration range tile by tile:
-//   * a segment that covers a whole tile runs the normal epilogue;
-//   * a segment that starts inside a tile (kb > 0; always the FIRST segment of a workgroup) writes
-//     its fp32 accumulators to the workgroup's slab and publishes a flag;
-//   * the segment that starts a tile (kb == 0) but does not end it is the tile's finisher: after
-//     its own K range it acquires the slabs of the following workgroups and runs the epilogue.
-// Producers never wait; a finisher only waits for segments other workgroups compute FIRST, so
-// there is no circular wait as long as all G workgroups are resident (G <= CU count, one
-// workgroup per CU by LDS).  Hand-off = guide G16: plain slab stores, every wave s_waitcnt
-// vmcnt(0), barrier, one lane agent-scope release + flag store; consumer: relaxed poll, one
-// agent-scope acquire, barrier, plain loads.  Flags are reset by their consumer, so the flag
-// region only has to be zero before the first launch.
-struct StreamKArgs {
-  float* slabs;          // [G][256*256] fp32
-  unsigned* flags;       // [G]
-  unsigned* error_word;  // set to 1 if a bounded spin gave up
-  int G;
-};
-
-#define SLAB_FLOATS (256 * 256)
-
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void dk_gemm256_streamk_kernel(GemmParams p, StreamKArgs sk) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int nbm = (p.M + T256 - 1) / T256, nbn = (p.N + T256 - 1) / T256;
-  const int nk = p.K / BK;
-  const long total = (long)nbm * nbn * nk;
-  // XCD-contiguous workgroup index: consecutive v (= neighbouring tiles) share an L2
-  const int G = sk.G;
-  int v;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = G >> 3, r = G & 7;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  auto wg_start = [&](int u) { return (long)u * total / G; };
-  long it = wg_start(v);
-  const long it_end = wg_start(v + 1);
-
-  while (it < it_end) {
-    const int tile = (int)(it / nk);
-    const int kb = (int)(it - (long)tile * nk);
-    const int ke = (int)min((long)nk, kb + (it_end - it));
-    const int GROUP = 4;
-    const int tpg = GROUP * nbn;
-    const int g = tile / tpg;
-    const int first_m = g * GROUP;
-    const int gsz = min(nbm - first_m, GROUP);
-    const int tm = first_m + (tile % tpg) % gsz;
-    const int tn = (tile % tpg) / gsz;
-    const int m0 = tm * T256, n0 = tn * T256;
-
-    unsigned src[4][2];  // byte offsets from p.A (0,1) / p.W (2,3): uniform base + 32-bit lane offset
-    {
-      const int srow = lane >> 3;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = wave * 16 + j * 8 + srow;
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int m = min(m0 + hh * 128 + r, p.M - 1);
-          const int phys = (m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len);
-          src[hh][j] = (unsigned)(((size_t)phys * p.lda + chunk * 8 + (size_t)kb * BK) * 2);
-          const int n = min(n0 + hh * 128 + r, p.N - 1);
-          src[2 + hh][j] = (unsigned)(((size_t)n * p.ldw + chunk * 8 + (size_t)kb * BK) * 2);
-        }
-      }
-    }
-    auto issue_tile = [&](int i) {  // i-th K-tile of this segment -> ring slot i & 1
-#pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
-        char* dst = smem + (i & 1) * KT_BYTES + hh * HALF_BYTES + (wave * 16) * 128;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(hh < 2 ? p.A : p.W) + (src[hh][j] + (unsigned)i * (BK * 2))),
-                                           (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
-      }
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nseg = ke - kb;
-    // register-pipelined K loop with hand-counted LDS waits (see VARIANT 4 of the tile-parallel kernel)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned sA = lds0 + wm * HALF_BYTES;
-    const unsigned sW = lds0 + (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
-#define DK_LDS_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
-#define DK_RD(SET, BUFOFF, KK)                                                  \
-  do {                                                                          \
-    const unsigned ok_ = (unsigned)swz_off(l31, (KK) * 2 + hi);                 \
-    const unsigned aA_ = ok_ + sA + (BUFOFF);                                   \
-    const unsigned aW_ = ok_ + sW + (BUFOFF);                                   \
-    DK_LDS_RD(wf##SET[0], aW_, 0);                                              \
-    DK_LDS_RD(wf##SET[1], aW_, 4096);                                           \
-    DK_LDS_RD(xf##SET[0], aA_, 0);                                              \
-    DK_LDS_RD(xf##SET[1], aA_, 4096);                                           \
-    DK_LDS_RD(xf##SET[2], aA_, 8192);                                           \
-    DK_LDS_RD(xf##SET[3], aA_, 12288);                                          \
-  } while (0)
-#define DK_WAIT(N, SET)                                                                                     \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                  \
-               : "+v"(wf##SET[0]), "+v"(wf##SET[1]), "+v"(xf##SET[0]), "+v"(xf##SET[1]), "+v"(xf##SET[2]), \
-                 "+v"(xf##SET[3]))
-#define DK_MM(SET)                                                                                            \
-  do {                                                                                                        \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)         \
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf##SET[ni], xf##SET[mi], acc[ni][mi], 0, 0, 0); \
-  } while (0)
-    bf16x8 wf0[2], xf0[4], wf1[2], xf1[4];
-    issue_tile(0);
-    if (nseg > 1) {
-      issue_tile(1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    DK_RD(0, 0u, 0);
-    for (int i = 0; i < nseg; ++i) {
-      const unsigned bo = (i & 1) * KT_BYTES;
-      DK_RD(1, bo, 1);
-      DK_WAIT(6, 0);
-      DK_MM(0);
-      DK_RD(0, bo, 2);
-      DK_WAIT(6, 1);
-      DK_MM(1);
-      DK_RD(1, bo, 3);
-      DK_WAIT(6, 0);
-      DK_MM(0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                   : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])
-                   :
-                   : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (i + 1 < nseg) DK_RD(0, bo ^ KT_BYTES, 0);
-      if (i + 2 < nseg) issue_tile(i + 2);
-      DK_MM(1);
-    }
-#undef DK_LDS_RD
-#undef DK_RD
-#undef DK_WAIT
-#undef DK_MM
-
-    // everything the tail needs per lane is derived from an id made opaque HERE, so that hipcc cannot
-    // hoist the epilogue / slab address arithmetic above the K loop (it spills LDS offsets into the
-    // loop otherwise, and a scratch reload costs a vmcnt(0) that drains the DMA pipeline)
-    int tid2 = tid;
-    asm volatile("" : "+v"(tid2));
-    const int hi2 = (tid2 >> 5) & 1, l31b = tid2 & 31;
-    if (kb > 0) {
-      // ---- producer: publish the partial accumulators (coalesced 16-byte stores) ----
-      float* slab = sk.slabs + (size_t)v * SLAB_FLOATS;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[ni][mi][4 * q4 + e];
-            *(f32x4*)(slab + ((size_t)((ni * 4 + mi) * 4 + q4) * 512 + tid2) * 4) = o;
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid2 == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(sk.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else {
-      if (ke < nk) {
-        // ---- finisher: add the slabs of the workgroups that cover [ke, nk) of this tile ----
-        const long tile_end = (long)(tile + 1) * nk;
-        for (int u = v + 1; u < G && wg_start(u) < tile_end; ++u) {
-          if (tid2 == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(sk.flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-              __builtin_amdgcn_s_sleep(4);
-              if (++spins > (1u << 24)) {  // ~ seconds: a producer never ran; give up loudly
-                __hip_atomic_store(sk.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          }
-          __syncthreads();
-          const float* slab = sk.slabs + (size_t)u * SLAB_FLOATS;
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 o = *(const f32x4*)(slab + ((size_t)((ni * 4 + mi) * 4 + q4) * 512 + tid2) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[ni][mi][4 * q4 + e] += o[e];
-                // at most 8 slab loads (32 registers) in flight next to the 128 accumulators
-                if (q4 == 3 && (mi & 1)) __builtin_amdgcn_sched_barrier(0);
-              }
-          __syncthreads();
-          if (tid2 == 0) __hip_atomic_store(sk.flags + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      dk_epilogue256(p, acc, m0, n0, wm, wn, hi2, l31b);
-    }
-    it += nseg;
-  }
-}
-
-size_t dk_streamk_workspace_bytes() { return (size_t)256 * SLAB_FLOATS * 4 + 4096; }
-
-int dk_launch_gemm256_streamk(const GemmParams& p, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  DK_REQUIRE(!p.conv, "gemm256 is a plain GEMM");
-  DK_REQUIRE(p.K % BK == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.lda % 8 == 0, "gemm256 alignment");
-  DK_REQUIRE(workspace != nullptr && workspace_bytes >= dk_streamk_workspace_bytes(), "stream-K workspace missing or too small");
-  DK_REQUIRE((size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.N * p.ldw * 2 < (1ull << 32), "stream-K operands must span < 4 GiB");
-  DK_REQUIRE(((uintptr_t)workspace & 255) == 0, "stream-K workspace must be 256-byte aligned");
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256_streamk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0;
-    DK_CHECK_HIP(hipGetDevice(&dev));
-    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
-  }
-  StreamKArgs sk;
-  sk.slabs = (float*)workspace;
-  sk.flags = (unsigned*)((char*)workspace + (size_t)256 * SLAB_FLOATS * 4);
-  sk.error_word = sk.flags + 512;
-  const int nbm = (p.M + T256 - 1) / T256, nbn = (p.N + T256 - 1) / T256;
-  const long total = (long)nbm * nbn * (p.K / BK);
-  int G = n_cu < 256 ? n_cu : 256;
-  if ((long)G > total) G = (int)total;
-  sk.G = G;
-  dk_prof_begin(0, 2.0 * (double)p.M * (double)p.N * (double)p.K, stream);
-  hipLaunchKernelGGL(dk_gemm256_streamk_kernel<0>, dim3(G), dim3(512), LDS_BYTES, stream, p, sk);
-  dk_prof_end(stream);
-  DK_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream) {
   DK_REQUIRE(!p.conv, "gemm256 is a plain GEMM");
   DK_REQUIRE(p.K % BK == 0 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.lda % 8 == 0, "gemm256 alignment");
