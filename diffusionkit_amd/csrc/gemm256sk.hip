@@ -26,9 +26,10 @@
 // publishes a flag; the segment that starts a tile is the tile's finisher: it adds the slabs of the
 // following workgroups and runs the epilogue.  Producers never wait and a finisher only waits for
 // segments that other workgroups compute first, so there is no circular wait while all G
-// workgroups are resident (one per CU by LDS).  Hand-off per guide G16: plain slab stores, every wave
-// s_waitcnt vmcnt(0), barrier, one lane agent-scope release + flag store; consumer: relaxed poll, one
-// agent-scope acquire, barrier, plain loads.  Flags are reset by their consumer.
+// workgroups are resident (one per CU by LDS).  Hand-off per guide G16 (R1): write-through (sc1) slab
+// stores, every wave s_waitcnt vmcnt(0), barrier, one relaxed agent-scope flag store -- deferred to the
+// first tile barrier of the workgroup's next segment so that the store drain hides under its DMA;
+// consumer: relaxed poll, one agent-scope acquire, barrier, plain loads.  Flags are reset by their consumer.
 #include <cstring>
 
 #include "dk_kernels.h"
@@ -50,6 +51,12 @@ struct SkArgs {
   unsigned* error_word;  // set to 1 when a bounded spin gave up
   int G;
 };
+
+// 16-byte write-through (sc1) store: the slab reaches memory without an agent-scope release fence
+// (buffer_wbl2 would write back every dirty line of the XCD's L2, other workgroups' C tiles included)
+__device__ __forceinline__ void store_sc1_b128(float* ptr, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
 
 __device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
   const unsigned sA = wm * HALF_BYTES;
   const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
 
+  bool publish_pending = false;  // slab stores issued, flag not yet published
   while (it < it_end) {
     const int tile = (int)(it / nk);
     const int kb = (int)(it - (long)tile * nk);
@@ -189,6 +197,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
                      : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (STREAMK && publish_pending) {
+          // the vmcnt(0) above also drained this wave's sc1 slab stores of the previous segment and
+          // every wave has passed the barrier: the slab is complete in memory -> publish the flag
+          if (tid == 0) __hip_atomic_store(sk.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          publish_pending = false;
+        }
         if (i + 1 < nseg) DK_RD(0, bo ^ KT_BYTES, 0);
         if (i + 2 < nseg) issue_tile(i + 2);
         DK_MM(1);
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
         f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
         const size_t slab_idx = (size_t)(wm * 128 + row) * 256 + wn * 64 + ni * 32 + rchunk * 4;
         if (producer) {
-          *(f32x4*)(sk.slabs + (size_t)v * SLAB_FLOATS + slab_idx) = a;
+          store_sc1_b128(sk.slabs + (size_t)v * SLAB_FLOATS + slab_idx, a);
           continue;
         }
         if (STREAMK && ke < nk) {
@@ -300,12 +314,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
     }
 
     if (producer) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(sk.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (it + nseg < it_end) {
+        publish_pending = true;  // published after the first tile barrier of the next segment (stores drain under its DMA)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sk.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (STREAMK && ke < nk) {
       __syncthreads();  // every wave has read the slabs

@@ -20,9 +20,25 @@ Tensor = torch.Tensor
 BF = torch.bfloat16
 
 
+def tune(key: str, value: int) -> None:
+    """dk_tune_set: kernel-variant knobs for A/B measurements and parity tests (-1 = automatic)."""
+    _lib.check(_lib.load().dk_tune_set(key.encode(), int(value)), "dk_tune_set")
+
+
+_gemm_ws = {}
+
+
+def gemm_workspace(device) -> Tensor:
+    """Zero-initialised stream-K scratch (dk_gemm_workspace_bytes), one per device."""
+    key = str(device)
+    if key not in _gemm_ws:
+        _gemm_ws[key] = torch.zeros(_lib.load().dk_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+    return _gemm_ws[key]
+
+
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: int = DK_EPI_BIAS,
            gate: Optional[Tensor] = None, res: Optional[Tensor] = None, gate_seg_len: int = 0,
-           alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+           alpha: float = 1.0, out: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> Tensor:
     """nn.Linear (+ fused epilogue).  x: [M, K]; w: [N, K]; gate: [n_batch, N]; res: [M, N]."""
     lib = _lib.load()
     for n, t in (("x", x), ("w", w)):
@@ -39,6 +55,8 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: int = 
     d.gate_seg_len = gate_seg_len
     d.gate_stride = gate.stride(0) if gate is not None else 0
     d.alpha, d.epilogue = alpha, epilogue
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel()
     _lib.check(lib.dk_gemm_bf16(C.byref(d), _stream()), "dk_gemm_bf16")
     return out
 

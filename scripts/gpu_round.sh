@@ -24,11 +24,19 @@ fi
 if has prof; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o flux -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/prof.log 2>&1)
   echo "prof exit $?" >> $OUT/prof.log; tail -n 3 $OUT/prof.log
-  find $OUT/prof -name "*stats*" | head; find $OUT/prof -name "*kernel_trace*" -size +20M -delete
+  python scripts/rocpd_summary.py $(find $OUT/prof -name "*.db" | head -1) --by-grid > $OUT/kernel_stats.md 2>&1; head -n 12 $OUT/kernel_stats.md
+  rm -rf $OUT/prof  # the rocpd database (10+ MiB per run) stays on the box; the summary travels
 fi
 if has pmc; then
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OLDPWD/$OUT/pmc_fetch -o flux -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/pmc_fetch.log 2>&1)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OLDPWD/$OUT/pmc_write -o flux -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/pmc_write.log 2>&1)
-  python scripts/pmc_summary.py $OUT > $OUT/pmc_summary.log 2>&1; tail -n 20 $OUT/pmc_summary.log
+  # counters in their own runs (kernel-trace only), CSV output; FETCH_SIZE and WRITE_SIZE cannot share a pass
+  for CNT in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+    TAGC=$(echo $CNT | cut -d" " -f1)
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CNT -d $OLDPWD/$OUT/pmc_$TAGC -o flux --output-format csv -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/pmc_$TAGC.log 2>&1)
+    echo "pmc $TAGC exit $?"
+    find $OUT/pmc_$TAGC -name "*kernel_trace.csv" -size +30M -delete
+  done
+  python scripts/pmc_traffic.py $OUT > $OUT/pmc_traffic.log 2>&1; tail -n 12 $OUT/pmc_traffic.log
+  { python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES gemm256v2; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES attn2; } > $OUT/pmc_sq.log 2>&1
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES  # raw CSVs exceed the 64 MiB pull limit
 fi
 ls -la $OUT

@@ -26,6 +26,13 @@ def main():
         print(f"| `{short}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * tot / total:.1f} "
               f"| {vg} | {ag} | {lds} | {grid} | {wg} |")
     print(f"\ntotal kernel time: {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    if "--by-grid" in sys.argv:
+        rows = cur.execute(
+            "select name, grid_x, count(*), sum(duration), avg(duration) from kernels where name like '%gemm%' or name like '%attn%' "
+            "group by name, grid_x order by sum(duration) desc").fetchall()
+        print("\n| kernel | grid_x (threads) | calls | total ms | avg us |\n|---|---|---|---|---|")
+        for name, grid, n, tot, avg in rows[:40]:
+            print(f"| `{name[:60]}` | {grid} | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} |")
     if "--pmc" in sys.argv:
         try:
             pr = cur.execute("select k.name, p.name, count(*), sum(e.value) from pmc_events e "

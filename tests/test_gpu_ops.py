@@ -91,6 +91,72 @@ def test_gemm_segment_mapping_in_place(dev):
     assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP
 
 
+GEMM_MODES = {128: "128^2 tiles", 0: "256^2 simple", 1: "256^2 staggered", 5: "256^2 register-pipelined",
+              6: "256^2 v2 (LDS-staged tail)", 3: "256^2 v2 stream-K"}
+
+
+@pytest.mark.parametrize("mode", sorted(GEMM_MODES))
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
+def test_gemm_kernel_variants(dev, mode, epi):
+    """Every GEMM kernel variant behind dk_tune_set("gemm", mode) against the oracle, on a shape all of
+    them accept (M, N multiples of 256; two row segments of 512), with a multi-tile K loop.  The
+    stream-K variant runs with more K-tile iterations than workgroups, so tiles are split and the
+    slab hand-off (producer / finisher) is exercised."""
+    from diffusionkit_amd import ops
+    B, S, K, N = 2, 512, 640, 768
+    M = B * S
+    x, w, b = randn(M, K, seed=14), randn(N, K, seed=15, scale=0.05), randn(N, seed=16, scale=0.1)
+    res, gate = randn(M, N, seed=17), randn(B, N, seed=18)
+    acc = bf16r(x @ w.t() + b)
+    ws = ops.gemm_workspace(dev)
+    try:
+        ops.tune("gemm", mode)
+        if epi == "bias":
+            y = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws)
+            ref = acc
+        elif epi == "gelu":
+            y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_BIAS_GELU, workspace=ws)
+            ref = om.gelu_erf(acc, Prec())
+        else:
+            y = ops.linear(g(x, dev), g(w, dev), g(b, dev), epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev),
+                           gate_seg_len=S, workspace=ws)
+            ref = res + bf16r(gate.repeat_interleave(S, 0) * acc)
+    finally:
+        ops.tune("gemm", -1)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP, GEMM_MODES[mode]
+    assert max_abs(ref, y.float()) < 0.02 * float(ref.abs().max()) + 1e-2
+    # the stream-K flag region must be left zero (flags are reset by their consumer)
+    assert int(ws[-4096:].sum()) == 0
+
+
+def test_gemm_streamk_joint_stream_in_place(dev):
+    """Stream-K / v2 kernels on the image rows of a joint [B, S, h] buffer (segment maps evaluated once
+    per tile), C aliasing the residual as in post_sdpa."""
+    from diffusionkit_amd import ops
+    B, S_t, S_i, h = 2, 256, 512, 256
+    S = S_t + S_i
+    att, X = randn(B, S, h, seed=9), randn(B, S, h, seed=10)
+    w, b, gate = randn(h, h, seed=11, scale=0.08), randn(h, seed=12, scale=0.1), randn(B, 3 * h, seed=13)
+    ref = X.clone()
+    o = bf16r(att[:, S_t:] @ w.t() + b)
+    ref[:, S_t:] = X[:, S_t:] + bf16r(gate[:, None, h:2 * h] * o)
+    ws = ops.gemm_workspace(dev)
+    for mode in (6, 3):
+        Xd, attd, gd = g(X, dev), g(att, dev), g(gate, dev)
+        try:
+            ops.tune("gemm", mode)
+            ops.gemm_desc_call(A=attd.data_ptr() + S_t * h * 2, W=g(w, dev), C=Xd.data_ptr() + S_t * h * 2, bias=g(b, dev),
+                               gate=gd.data_ptr() + h * 2, res=Xd.data_ptr() + S_t * h * 2, M=B * S_i, N=h, K=h, lda=h, ldc=h, ldr=h,
+                               a_seg_len=S_i, a_seg_stride=S, c_seg_len=S_i, c_seg_stride=S, r_seg_len=S_i, r_seg_stride=S,
+                               gate_seg_len=S_i, gate_stride=3 * h, alpha=1.0, epilogue=ops.DK_EPI_GATE_RES,
+                               workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+        finally:
+            ops.tune("gemm", -1)
+        got = Xd.float().cpu()
+        assert torch.equal(got[:, :S_t], X[:, :S_t])
+        assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP, mode
+
+
 # ---- conv ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C,O,ups,res", [(1, 16, 16, 64, 128, False, False), (2, 8, 24, 128, 64, False, True),
                                                (1, 16, 8, 64, 64, True, False), (1, 32, 32, 128, 3, False, False)])
@@ -125,6 +191,25 @@ def test_attention(dev, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64)])
+def test_attention_kernel_variants(dev, mode, B, H, S, D):
+    """Every attention kernel variant behind dk_tune_set("attn", mode) (4 / 8 waves, interleaved score
+    chains, the VALU-lean kernel with the deferred rescale) against the oracle; ragged tail tile."""
+    from diffusionkit_amd import ops
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=32)
+    try:
+        ops.tune("attn", mode)
+        y = ops.attention(g(qkv, dev), H, D)
+    finally:
+        ops.tune("attn", -1)
+    q, k, v = (qkv[..., i * h:(i + 1) * h].reshape(B, S, H, D).transpose(1, 2) for i in range(3))
+    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(B, S, h)
+    assert rel_l2(ref, y.float()) < 6e-3
+    assert max_abs(ref, y.float()) < 0.03
+
+
 def test_attention_spiked_key_forces_rescale(dev):
     """A key that dominates late in the sequence forces the online-softmax rescale path
     (guide rule 26); fp64 reference."""
@@ -133,12 +218,17 @@ def test_attention_spiked_key_forces_rescale(dev):
     h = H * D
     qkv = randn(B, S, 3 * h, seed=31, scale=0.5)
     qkv[0, 250, h:2 * h] = bf16r(qkv[0, 7, :h] * 6.0)  # key 250 aligned with query 7
-    y = ops.attention(g(qkv, dev), H, D)
     q, k, v = (qkv[..., i * h:(i + 1) * h].double() for i in range(3))
     p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
     ref = (p @ v[0])[None]
-    assert rel_l2(ref, y.float()) < 6e-3
     assert float(p[7, 250]) > 0.9
+    for mode in (0, 4, 5):  # always-rescale kernel and the deferred-rescale kernels (threshold path)
+        try:
+            ops.tune("attn", mode)
+            y = ops.attention(g(qkv, dev), H, D)
+        finally:
+            ops.tune("attn", -1)
+        assert rel_l2(ref, y.float()) < 6e-3, mode
 
 
 # ---- normalisation / elementwise ------------------------------------------------------------------
