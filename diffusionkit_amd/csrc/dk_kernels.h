@@ -41,7 +41,10 @@ extern int g_dk_gemm_mode;
 // -- the flag region -- must be zero before the first launch; kernels leave it zero)
 size_t dk_streamk_workspace_bytes();
 bool dk_gemm256v2_eligible(const GemmParams& p);
-int dk_launch_gemm256v2(const GemmParams& p, bool streamk, hipStream_t stream);  // gemm256sk.hip
+int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk, hipStream_t stream);  // gemm256sk.hip
+// two problems with the same N, K, epilogue in one launch (image + text stream of a double block); falls
+// back to two launches when the pair is not eligible for the grouped kernel
+int dk_launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t stream);
 
 // optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention
 void dk_prof_begin(int cls, double work, hipStream_t st);

@@ -164,6 +164,22 @@ struct Carver {
   }
 };
 
+static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
+                                bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
+                                const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
+                                int r_seg_stride) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.gate = gate; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+  p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride;
+  p.c_seg_len = c_seg_len; p.c_seg_stride = c_seg_stride;
+  p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
+  p.gate_seg_len = gate_seg_len > 0 ? gate_seg_len : M; p.gate_stride = gate_stride;
+  p.alpha = 1.0f; p.epi = epi;
+  return p;
+}
+
 static int linear_call(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                        bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
                        const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
@@ -351,7 +367,7 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->XN = (bf16_t*)c.take(BS * h * 2);
   m->QKV = (bf16_t*)c.take(BS * 3 * h * 2);
   m->ATT = (bf16_t*)c.take(BS * h * 2);
-  const size_t hid = (size_t)B * (S_i > S_t ? S_i : S_t) * m->cfg.mlp_ratio * h * 2;
+  const size_t hid = BS * m->cfg.mlp_ratio * h * 2;  // MLP hidden of both streams of a double block (image rows first)
   const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)(1 + m->cfg.mlp_ratio) * h * 2 : 0;
   m->CAT = (bf16_t*)c.take(cat > hid ? cat : hid);  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
   m->HID = m->CAT;
@@ -473,18 +489,71 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
                      c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
 
-  // MultiModalTransformerBlock x depth_multimodal (mmdit.py:568-675)
+  // MultiModalTransformerBlock x depth_multimodal (mmdit.py:568-675).  The two streams run the same
+  // Linear shapes on different weights; their GEMMs are issued as pairs so that the 256 x 256 kernel can
+  // place the text tiles in the same wave as the image tiles (dk_launch_gemm_pair).
+  bf16_t* XN_img = m->XN;
+  bf16_t* XN_txt = m->XN + (size_t)B * S_i * h;
+  bf16_t* HID_img = m->HID;
+  bf16_t* HID_txt = m->HID + (size_t)B * S_i * r * h;
+  bf16_t* X_img = m->X + (size_t)S_t * h;
+  bf16_t* X_txt = m->X;
+  const int Mi = B * S_i, Mt = B * S_t;
   for (int i = 0; i < c.depth_multimodal; ++i) {
     const bf16_t* mod_img = mod_step + (size_t)m->mod_offset(0, i) * h;
     const bf16_t* mod_txt = mod_step + (size_t)m->mod_offset(1, i) * h;
-    DK_TRY(pre_sdpa(m, m->dimg[i], S_t, S_i, mod_img, mod_stride, st));
-    DK_TRY(pre_sdpa(m, m->dtxt[i], 0, S_t, mod_txt, mod_stride, st));
+    const StreamW& wi = m->dimg[i];
+    const StreamW& wt = m->dtxt[i];
+    const bool txt_post = !m->txt_skipped(i);
+    // pre_sdpa (mmdit.py:440-519): LN-modulate, q/k/v projection, QK-norm (+ RoPE)
+    DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img, mod_img + h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
+    DK_TRY(dk_launch_ln_modulate(X_txt, h, XN_txt, h, Mt, h, mod_txt, mod_txt + h, mod_stride, S_t, S_t, S, c.layer_norm_eps, st));
+    DK_TRY(dk_launch_gemm_pair(
+        linear_params(XN_img, h, Mi, 0, wi.qkv_w, wi.qkv_b, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S, Mi, 3 * h, h, DK_EPI_BIAS, nullptr,
+                      0, 0, nullptr, 0, 0, 0),
+        linear_params(XN_txt, h, Mt, 0, wt.qkv_w, wt.qkv_b, m->QKV, 3 * h, S_t, S, Mt, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0,
+                      0, 0),
+        st));
+    DK_TRY(dk_launch_qk_norm_rope(m->QKV + (size_t)S_t * 3 * h, 3 * h, 0, h, Mi, c.num_heads, m->D(), wi.qn, wi.kn, 1e-6f,
+                                  c.use_rope ? m->rope : nullptr, S_i, S, S_t, S, st));
+    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, Mt, c.num_heads, m->D(), wt.qn, wt.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
+                                  S_t, S, 0, S, st));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
     DK_TRY(dk_launch_attention(ap, st));
-    DK_TRY(post_sdpa_seq(m, m->dimg[i], S_t, S_i, mod_img, mod_stride, st));
-    if (!m->txt_skipped(i)) DK_TRY(post_sdpa_seq(m, m->dtxt[i], 0, S_t, mod_txt, mod_stride, st));
+    // post_sdpa, sequential form (mmdit.py:537-548): residual += gate_attn * o_proj(attn)
+    const GemmParams o_img = linear_params(m->ATT + (size_t)S_t * h, h, S_i, S, wi.o_w, wi.o_b, X_img, h, S_i, S, Mi, h, h, DK_EPI_GATE_RES,
+                                           mod_img + 2 * h, S_i, mod_stride, X_img, h, S_i, S);
+    if (txt_post) {
+      DK_TRY(dk_launch_gemm_pair(o_img,
+                                 linear_params(m->ATT, h, S_t, S, wt.o_w, wt.o_b, X_txt, h, S_t, S, Mt, h, h, DK_EPI_GATE_RES,
+                                               mod_txt + 2 * h, S_t, mod_stride, X_txt, h, S_t, S),
+                                 st));
+    } else {
+      DK_TRY(dk_launch_gemm(o_img, st));
+    }
+    // residual += gate_mlp * fc2(gelu(fc1(LN-mod(residual))))
+    DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img + 3 * h, mod_img + 4 * h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
+    const GemmParams fc1_img = linear_params(XN_img, h, Mi, 0, wi.fc1_w, wi.fc1_b, HID_img, r * h, Mi, 0, Mi, r * h, h, DK_EPI_BIAS_GELU,
+                                             nullptr, 0, 0, nullptr, 0, 0, 0);
+    const GemmParams fc2_img = linear_params(HID_img, r * h, Mi, 0, wi.fc2_w, wi.fc2_b, X_img, h, S_i, S, Mi, h, r * h, DK_EPI_GATE_RES,
+                                             mod_img + 5 * h, S_i, mod_stride, X_img, h, S_i, S);
+    if (txt_post) {
+      DK_TRY(dk_launch_ln_modulate(X_txt, h, XN_txt, h, Mt, h, mod_txt + 3 * h, mod_txt + 4 * h, mod_stride, S_t, S_t, S, c.layer_norm_eps,
+                                   st));
+      DK_TRY(dk_launch_gemm_pair(fc1_img,
+                                 linear_params(XN_txt, h, Mt, 0, wt.fc1_w, wt.fc1_b, HID_txt, r * h, Mt, 0, Mt, r * h, h,
+                                               DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr, 0, 0, 0),
+                                 st));
+      DK_TRY(dk_launch_gemm_pair(fc2_img,
+                                 linear_params(HID_txt, r * h, Mt, 0, wt.fc2_w, wt.fc2_b, X_txt, h, S_t, S, Mt, h, r * h, DK_EPI_GATE_RES,
+                                               mod_txt + 5 * h, S_t, mod_stride, X_txt, h, S_t, S),
+                                 st));
+    } else {
+      DK_TRY(dk_launch_gemm(fc1_img, st));
+      DK_TRY(dk_launch_gemm(fc2_img, st));
+    }
   }
 
   // UnifiedTransformerBlock x depth_unified (mmdit.py:693-751), parallel attention + MLP

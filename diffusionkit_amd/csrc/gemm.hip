@@ -247,16 +247,16 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const bool sk_ok = v2_ok && p.workspace != nullptr && p.M >= 1024;
     if (g_dk_gemm_mode == 3) {
       DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
-      return dk_launch_gemm256v2(p, true, stream);
+      return dk_launch_gemm256v2(p, nullptr, true, stream);
     }
     if (g_dk_gemm_mode == 6) {
       DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
-      return dk_launch_gemm256v2(p, false, stream);
+      return dk_launch_gemm256v2(p, nullptr, false, stream);
     }
     if (g_dk_gemm_mode >= 0 && g_dk_gemm_mode < 128) return dk_launch_gemm256(p, g_dk_gemm_mode, stream);
     // automatic choice (kernel lab, profiles/r01_gemm_lab_v2.log): the second-generation 256^2 kernel wins
     // on every eligible large-M shape; ineligible shapes fall back to the first 256^2 kernel / 128^2 tiles
-    if (v2_ok && p.M >= 1024) return dk_launch_gemm256v2(p, false, stream);
+    if (v2_ok && p.M >= 1024) return dk_launch_gemm256v2(p, nullptr, false, stream);
     if (prefer_256(p)) return dk_launch_gemm256(p, 5, stream);
   }
   DK_REQUIRE(p.K % BK == 0, "K must be a multiple of 64");
@@ -285,4 +285,20 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t stream) {
+  GemmParams a = a_in, b = b_in;
+  if (a.ldw <= 0) a.ldw = a.K;
+  if (b.ldw <= 0) b.ldw = b.K;
+  const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha;
+  if (g_dk_gemm_mode == -1 && same && dk_gemm256v2_eligible(a) && dk_gemm256v2_eligible(b)) {
+    // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial
+    // extra wave costs more than the small separate launch)
+    const long ta = (long)(a.M / 256) * (a.N / 256), tb = (long)(b.M / 256) * (b.N / 256);
+    if ((ta + 255) / 256 == (ta + tb + 255) / 256) return dk_launch_gemm256v2(a, &b, false, stream);
+  }
+  int rc = dk_launch_gemm(a, stream);
+  if (rc) return rc;
+  return dk_launch_gemm(b, stream);
 }

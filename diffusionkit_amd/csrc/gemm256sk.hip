@@ -60,8 +60,13 @@ __device__ __forceinline__ void store_sc1_b128(float* ptr, f32x4 v) {
 
 __device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
+// Grouped form: the launch covers the tiles of problem `pa` followed by the tiles of an optional second
+// problem `pb` with the same N, K and epilogue kind but its own operands, row maps and M (the text
+// stream of a double block next to its image stream: mmdit.py:568-675 runs the same Linear shapes on
+// both).  The 12 + 192 tiles of the two streams then share one wave of the 256 CUs instead of the
+// text stream running alone on 48 small tiles.
 template <bool STREAMK>
-__global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkArgs sk) {
+__global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, SkArgs sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
   const int tid = threadIdx.x;
@@ -70,10 +75,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
   const int wm = wave >> 2, wn = wave & 3;
   const int hi = lane >> 5, l31 = lane & 31;
 
-  const int nbm = p.M / T256, nbn = p.N / T256;
-  const int nk = p.K / BK;
-  const long total = (long)nbm * nbn * nk;
-  const int G = STREAMK ? sk.G : nbm * nbn;
+  const int nk = pa.K / BK;
+  const long total = (long)(tiles_a + tiles_b) * nk;
+  const int G = STREAMK ? sk.G : tiles_a + tiles_b;
   int v;  // XCD-contiguous workgroup index: neighbouring tiles share an L2
   {
     const int bid = blockIdx.x;
@@ -84,15 +88,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
   long it = wg_start(v);
   const long it_end = wg_start(v + 1);
 
-  // ---- lane-constant parts of the DMA source offsets and of the LDS fragment addresses ----
+  // ---- lane-constant parts of the LDS fragment addresses ----
   const int srow = lane >> 3;
-  unsigned la[2], lw[2];  // lane part of the A / W source byte offset for DMA instruction j
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
-    la[j] = ((unsigned)srow * (unsigned)p.lda + chunk * 8) * 2u;
-    lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
-  }
   unsigned offk[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) offk[kk] = (unsigned)swz128(l31, kk * 2 + hi);
@@ -102,16 +99,27 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams p, SkAr
   bool publish_pending = false;  // slab stores issued, flag not yet published
   while (it < it_end) {
     const int tile = (int)(it / nk);
+    const bool second = tile >= tiles_a;
+    const GemmParams& p = second ? pb : pa;
+    const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
+    const int nbm = p.M / T256, nbn = p.N / T256;
+    unsigned la[2], lw[2];  // lane part of the A / W source byte offset for DMA instruction j
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
+      la[j] = ((unsigned)srow * (unsigned)p.lda + chunk * 8) * 2u;
+      lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
+    }
     const int kb = (int)(it - (long)tile * nk);
     const int ke = (int)min((long)nk, kb + (it_end - it));
     const int nseg = ke - kb;
     const int GROUP = 4;
     const int tpg = GROUP * nbn;
-    const int g = tile / tpg;
+    const int g = tl / tpg;
     const int first_m = g * GROUP;
     const int gsz = min(nbm - first_m, GROUP);
-    const int tm = first_m + (tile % tpg) % gsz;
-    const int tn = (tile % tpg) / gsz;
+    const int tm = first_m + (tl % tpg) % gsz;
+    const int tn = (tl % tpg) / gsz;
     const int m0 = tm * T256, n0 = tn * T256;
 
     // tile-uniform source bases (bytes): rows m0 + hh*128 + wave*16 + j*8 (+ srow in the lane part)
@@ -340,8 +348,12 @@ bool dk_gemm256v2_eligible(const GemmParams& p) {
 
 size_t dk_streamk_workspace_bytes() { return (size_t)256 * SLAB_FLOATS * 4 + 4096; }
 
-int dk_launch_gemm256v2(const GemmParams& p, bool streamk, hipStream_t stream) {
+int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk, hipStream_t stream) {
   DK_REQUIRE(dk_gemm256v2_eligible(p), "gemm256v2: shape / segment map not eligible");
+  if (p2) {
+    DK_REQUIRE(dk_gemm256v2_eligible(*p2), "gemm256v2: second problem not eligible");
+    DK_REQUIRE(p2->N == p.N && p2->K == p.K && p2->epi == p.epi && p2->alpha == p.alpha, "grouped GEMM: N, K, epilogue must match");
+  }
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
@@ -354,25 +366,29 @@ int dk_launch_gemm256v2(const GemmParams& p, bool streamk, hipStream_t stream) {
   }
   SkArgs sk;
   memset(&sk, 0, sizeof(sk));
-  const int nbm = p.M / T256, nbn = p.N / T256;
-  int grid = nbm * nbn;
+  const int tiles_a = (p.M / T256) * (p.N / T256);
+  const int tiles_b = p2 ? (p2->M / T256) * (p2->N / T256) : 0;
+  int grid = tiles_a + tiles_b;
   if (streamk) {
     DK_REQUIRE(p.workspace != nullptr && p.workspace_bytes >= dk_streamk_workspace_bytes(), "stream-K workspace missing or too small");
     DK_REQUIRE(((uintptr_t)p.workspace & 255) == 0, "stream-K workspace must be 256-byte aligned");
     sk.slabs = (float*)p.workspace;
     sk.flags = (unsigned*)((char*)p.workspace + (size_t)256 * SLAB_FLOATS * 4);
     sk.error_word = sk.flags + 512;
-    const long total = (long)nbm * nbn * (p.K / BK);
+    const long total = (long)grid * (p.K / BK);
     int G = n_cu < 256 ? n_cu : 256;
     if ((long)G > total) G = (int)total;
     sk.G = G;
     grid = G;
   }
-  dk_prof_begin(0, 2.0 * (double)p.M * (double)p.N * (double)p.K, stream);
+  double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
+  dk_prof_begin(0, work, stream);
+  const GemmParams& pb = p2 ? *p2 : p;
   if (streamk)
-    hipLaunchKernelGGL(dk_gemm256v2_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, stream, p, sk);
+    hipLaunchKernelGGL(dk_gemm256v2_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   else
-    hipLaunchKernelGGL(dk_gemm256v2_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, p, sk);
+    hipLaunchKernelGGL(dk_gemm256v2_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
