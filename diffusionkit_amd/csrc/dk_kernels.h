@@ -33,6 +33,13 @@ struct GemmParams {
   const bf16_t* zeros;  // >= 128 B of zeros (padding taps)
   void* workspace;      // optional stream-K workspace (dk_streamk_workspace_bytes()), else null
   size_t workspace_bytes;
+  // optional column split (256^2 v2 kernel only): output columns >= n_split go to C2 (leading dim ldc2, same row
+  // map as C, column index rebased to 0) with epilogue epi2 -- the fused linear1 of the single-stream blocks
+  // (q/k/v projection | fc1 + GELU over one read of the modulated activations, mmdit.py:693-751)
+  int n_split;
+  bf16_t* C2;
+  int ldc2;
+  int epi2;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
 int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream);  // gemm256.hip

@@ -304,15 +304,24 @@ static int need(const std::unordered_map<std::string, const void*>& named, const
 
 static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool single, bool skip_post) {
   const auto& n = m->named;
-  DK_TRY(need(n, p + ".attn.qkv.weight", &w.qkv_w));
-  DK_TRY(need(n, p + ".attn.qkv.bias", &w.qkv_b));
+  if (single) {  // fused [q|k|v|fc1] matrix; fc1 views point into it
+    DK_TRY(need(n, p + ".linear1.weight", &w.qkv_w));
+    DK_TRY(need(n, p + ".linear1.bias", &w.qkv_b));
+    w.fc1_w = w.qkv_w + (size_t)3 * m->h() * m->h();
+    w.fc1_b = w.qkv_b + 3 * m->h();
+  } else {
+    DK_TRY(need(n, p + ".attn.qkv.weight", &w.qkv_w));
+    DK_TRY(need(n, p + ".attn.qkv.bias", &w.qkv_b));
+  }
   if (m->cfg.use_qk_norm) {
     DK_TRY(need(n, p + ".qk_norm.q_norm.weight", &w.qn));
     DK_TRY(need(n, p + ".qk_norm.k_norm.weight", &w.kn));
   }
   if (skip_post) return 0;
-  DK_TRY(need(n, p + ".mlp.fc1.weight", &w.fc1_w));
-  DK_TRY(need(n, p + ".mlp.fc1.bias", &w.fc1_b));
+  if (!single) {
+    DK_TRY(need(n, p + ".mlp.fc1.weight", &w.fc1_w));
+    DK_TRY(need(n, p + ".mlp.fc1.bias", &w.fc1_b));
+  }
   if (single) {
     DK_TRY(need(n, p + ".linear2.weight", &w.l2_w));
     DK_TRY(need(n, p + ".linear2.bias", &w.l2_b));
@@ -562,10 +571,12 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
     const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
     const int M = B * S, ldcat = (1 + r) * h;
     DK_TRY(dk_launch_ln_modulate(m->X, h, m->XN, h, M, h, mod, mod + h, mod_stride, S, M, 0, c.layer_norm_eps, st));
-    DK_TRY(linear_call(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0,
-                       0, st));
-    DK_TRY(linear_call(m->XN, h, M, 0, w.fc1_w, w.fc1_b, m->CAT + h, ldcat, M, 0, M, r * h, h, DK_EPI_BIAS_GELU, nullptr, 0, 0,
-                       nullptr, 0, 0, 0, st));
+    {  // linear1: [q|k|v] -> QKV, gelu(fc1) -> CAT[:, h:], one pass over the modulated activations
+      GemmParams l1 = linear_params(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, (3 + r) * h, h, DK_EPI_BIAS, nullptr, 0, 0,
+                                    nullptr, 0, 0, 0);
+      l1.n_split = 3 * h; l1.C2 = m->CAT + h; l1.ldc2 = ldcat; l1.epi2 = DK_EPI_BIAS_GELU;
+      DK_TRY(dk_launch_gemm(l1, st));
+    }
     DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
                                   S, S, 0, S, st));
     AttnParams ap;

@@ -242,6 +242,16 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   if (p.ldw <= 0) p.ldw = p.K;
   DK_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
+  if (p.n_split > 0 && !(g_dk_gemm_mode == -1 && dk_gemm256v2_eligible(p) && p.M >= 1024)) {
+    // column-split GEMM on a kernel without split support: two GEMMs over the two column ranges
+    DK_REQUIRE(p.n_split < p.N && p.C2 != nullptr, "bad column split");
+    GemmParams a = p, b = p;
+    a.N = p.n_split; a.n_split = 0;
+    b.N = p.N - p.n_split; b.n_split = 0; b.W = p.W + (size_t)p.n_split * p.ldw; b.bias = p.bias ? p.bias + p.n_split : nullptr;
+    b.C = p.C2; b.ldc = p.ldc2; b.epi = p.epi2;
+    const int rc = dk_launch_gemm(a, stream);
+    return rc ? rc : dk_launch_gemm(b, stream);
+  }
   if (!p.conv && g_dk_gemm_mode != 128 && p.N % 4 == 0 && p.K % 64 == 0 && p.lda % 8 == 0) {
     const bool v2_ok = dk_gemm256v2_eligible(p);
     const bool sk_ok = v2_ok && p.workspace != nullptr && p.M >= 1024;

@@ -224,6 +224,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
     // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
     // All waves passed the last loop barrier after their final ds_read, so the ring is free.
     const bool producer = STREAMK && kb > 0;
+    const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
+    bf16_t* const Cb = out2 ? p.C2 : p.C;
+    const int ldcb = out2 ? p.ldc2 : p.ldc;
+    const int epi = out2 ? p.epi2 : p.epi;
+    const int ncol0 = out2 ? n0 - p.n_split : n0;
     const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
     const size_t physR0 = (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128;
     const bf16_t* gate_row = p.gate ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
           *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((2 * g4 + hi) ^ (row & 7)) << 4)) = o;
         }
       // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
-      const int col = n0 + wn * 64 + ni * 32 + rchunk * 4;
+      const int col = n0 + wn * 64 + ni * 32 + rchunk * 4;       // column of the GEMM (bias, gate, residual)
+      const int ocol = ncol0 + wn * 64 + ni * 32 + rchunk * 4;   // column inside the output it goes to
       float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gate4[4] = {0.f, 0.f, 0.f, 0.f};
       if (!producer) {
         if (p.bias) {
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
           unpack2bf(bb.x, bias4[0], bias4[1]);
           unpack2bf(bb.y, bias4[2], bias4[3]);
         }
-        if (p.epi == DK_EPI_GATE_RES) {
+        if (epi == DK_EPI_GATE_RES) {
           const uint2 gg = *(const uint2*)(gate_row + col);
           unpack2bf(gg.x, gate4[0], gate4[1]);
           unpack2bf(gg.y, gate4[2], gate4[3]);
@@ -295,18 +301,18 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
         float vv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
-        if (p.epi == DK_EPI_BIAS_GELU) {
+        if (epi == DK_EPI_BIAS_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = gelu_erf_f(vv[e]);
-        } else if (p.epi == DK_EPI_BIAS_SILU) {
+        } else if (epi == DK_EPI_BIAS_SILU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = silu_f(vv[e]);
-        } else if (p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES) {
+        } else if (epi == DK_EPI_GATE_RES || epi == DK_EPI_RES) {
           const uint2 rr = *(const uint2*)(p.res + (physR0 + row) * (size_t)p.ldr + col);
           float r4[4];
           unpack2bf(rr.x, r4[0], r4[1]);
           unpack2bf(rr.y, r4[2], r4[3]);
-          if (p.epi == DK_EPI_GATE_RES) {
+          if (epi == DK_EPI_GATE_RES) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) vv[e] = r4[e] + round_bf16(gate4[e] * vv[e]);
           } else {
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
         uint2 o2;
         o2.x = pack2bf(vv[0], vv[1]);
         o2.y = pack2bf(vv[2], vv[3]);
-        *(uint2*)(p.C + (physC0 + row) * (size_t)p.ldc + col) = o2;
+        *(uint2*)(Cb + (physC0 + row) * (size_t)ldcb + ocol) = o2;
       }
     }
 
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
 
 bool dk_gemm256v2_eligible(const GemmParams& p) {
   auto seg_ok = [&](int len) { return len >= p.M || len % 256 == 0; };
-  return !p.conv && p.M % 256 == 0 && p.N % 256 == 0 && p.K % BK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0 &&
+  return !p.conv && p.n_split % 256 == 0 && (p.n_split == 0 || (p.C2 != nullptr && p.ldc2 % 4 == 0)) && p.M % 256 == 0 && p.N % 256 == 0 && p.K % BK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0 &&
          seg_ok(p.a_seg_len) && seg_ok(p.c_seg_len) && (p.res == nullptr || (seg_ok(p.r_seg_len) && p.ldr % 4 == 0)) &&
          (p.gate == nullptr || seg_ok(p.gate_seg_len)) && (size_t)p.lda * 2 * 8 < (1ull << 31) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
 }

@@ -10,7 +10,7 @@ so a real checkpoint loader ("next" row f1) only has to produce the same dict.
 ``pack_mmdit`` / ``pack_vae`` turn that dict into the fused, K-major bf16 tensors the HIP
 engine binds by name:
   * q/k/v projections -> one [3h, h] matrix, bias [3h] with a zero k part (quirk Q9);
-  * single blocks: o_proj | fc2 -> linear2 [h, 5h] with ONE bias (quirk Q8);
+  * single blocks: q|k|v|fc1 -> linear1 [7h, h]; o_proj | fc2 -> linear2 [h, 5h] with ONE bias (quirk Q8);
   * all adaLN_modulation Linears -> one [rows*h, h] matrix in the engine's row order;
   * conv weights [O,3,3,I] -> [O, 9*I] (already K-major in the MLX layout), conv_in padded to I=64.
 """
@@ -174,16 +174,23 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
 
     def stream(prefix, single=False, skip_post=False):
         q, k, v = (get(f"{prefix}.attn.{n}_proj.weight").to(dev) for n in "qkv")
-        put(prefix + ".attn.qkv.weight", torch.cat([q, k, v], dim=0))
         qb, vb = get(f"{prefix}.attn.q_proj.bias").to(dev), get(f"{prefix}.attn.v_proj.bias").to(dev)
-        put(prefix + ".attn.qkv.bias", torch.cat([qb, torch.zeros_like(qb), vb], dim=0))
+        if single:
+            # single-stream blocks: q/k/v and fc1 read the same modulated activations (mmdit.py:693-751;
+            # the BFL checkpoint stores them as one "linear1", model_io.py:224-252) -> one [7h, h] matrix
+            put(prefix + ".linear1.weight", torch.cat([q, k, v, get(prefix + ".mlp.fc1.weight").to(dev)], dim=0))
+            put(prefix + ".linear1.bias", torch.cat([qb, torch.zeros_like(qb), vb, get(prefix + ".mlp.fc1.bias").to(dev)], dim=0))
+        else:
+            put(prefix + ".attn.qkv.weight", torch.cat([q, k, v], dim=0))
+            put(prefix + ".attn.qkv.bias", torch.cat([qb, torch.zeros_like(qb), vb], dim=0))
         if cfg.use_qk_norm:
             put(prefix + ".qk_norm.q_norm.weight", get(prefix + ".qk_norm.q_norm.weight"))
             put(prefix + ".qk_norm.k_norm.weight", get(prefix + ".qk_norm.k_norm.weight"))
         if skip_post:
             return
-        put(prefix + ".mlp.fc1.weight", get(prefix + ".mlp.fc1.weight"))
-        put(prefix + ".mlp.fc1.bias", get(prefix + ".mlp.fc1.bias"))
+        if not single:
+            put(prefix + ".mlp.fc1.weight", get(prefix + ".mlp.fc1.weight"))
+            put(prefix + ".mlp.fc1.bias", get(prefix + ".mlp.fc1.bias"))
         if single:
             put(prefix + ".linear2.weight",
                 torch.cat([get(prefix + ".attn.o_proj.weight").to(dev), get(prefix + ".mlp.fc2.weight").to(dev)], dim=1))

@@ -84,6 +84,12 @@ def test_pack_mmdit_shapes():
             assert p[s0 + ".linear2.weight"].shape == (h, 5 * h)
             assert torch.equal(p[s0 + ".linear2.weight"][:, :h], w[s0 + ".attn.o_proj.weight"])
             assert torch.equal(p[s0 + ".linear2.bias"], w[s0 + ".attn.o_proj.bias"])  # one bias (quirk Q8)
+            # fused linear1 = [q | k | v | fc1] over one read of the modulated activations
+            assert p[s0 + ".linear1.weight"].shape == ((3 + cfg.mlp_ratio) * h, h)
+            assert torch.equal(p[s0 + ".linear1.weight"][2 * h:3 * h], w[s0 + ".attn.v_proj.weight"])
+            assert torch.equal(p[s0 + ".linear1.weight"][3 * h:], w[s0 + ".mlp.fc1.weight"])
+            assert torch.all(p[s0 + ".linear1.bias"][h:2 * h] == 0)
+            assert torch.equal(p[s0 + ".linear1.bias"][3 * h:], w[s0 + ".mlp.fc1.bias"])
         first = adaln_order(cfg)[0]
         assert torch.equal(p["adaLN.weight"][:6 * h], w[first + ".adaLN_modulation.layers.1.weight"])
         blob, index = blob_pack(p)
