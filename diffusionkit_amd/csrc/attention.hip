@@ -266,6 +266,7 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
     DK_ATTN_CASE(3, 8, 1)
     case 4: rc = dk_launch_attention2(p, 4, stream); break;
     case 5: rc = dk_launch_attention2(p, 8, stream); break;
+    case 6: rc = dk_launch_attention2(p, 7, stream); break;
     default: DK_REQUIRE(false, "unknown attention variant");
   }
 #undef DK_ATTN_CASE

@@ -26,7 +26,9 @@ struct Attn2Cfg {
   static constexpr int ROWB = D * 2;
   static constexpr int TILE_BYTES = KV * D * 2;
   static constexpr int NT = NW * 64;
-  static constexpr int NCH = KV * D / 8 / NT;
+  static constexpr int NCHUNK = KV * D / 8;                 // 16-byte chunks per K (or V) tile
+  static constexpr int NCH = (NCHUNK + NT - 1) / NT;        // per thread (the last one may be partial: NW = 7)
+  static constexpr bool RAGGED = (NCHUNK % NT) != 0;
   static constexpr int CPR = D / 8;
   static constexpr int QB = NW * 32;
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2] V[2]
@@ -79,13 +81,16 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
   }
 
   // ---- per-thread constants: staging chunk coordinates, global lane offsets, LDS offsets ----
+  bool st_on[C::NCH];       // chunk exists (NT does not divide the chunk count for 7-wave workgroups)
   unsigned g_off[C::NCH];   // byte offset of chunk i inside a 64-key tile (key-local row, 16-byte column)
   unsigned ks_off[C::NCH];  // LDS store offset inside a K tile
   unsigned vs_off[C::NCH];  // LDS store offset inside a V tile
   int st_kl[C::NCH];
 #pragma unroll
   for (int i = 0; i < C::NCH; ++i) {
-    const int id = tid + C::NT * i;
+    const int id0 = tid + C::NT * i;
+    st_on[i] = !C::RAGGED || id0 < C::NCHUNK;
+    const int id = st_on[i] ? id0 : 0;
     const int kl = id / C::CPR, c8 = id % C::CPR;
     st_kl[i] = kl;
     g_off[i] = (unsigned)kl * row_bytes + (unsigned)c8 * 16u;
@@ -107,12 +112,14 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
     if (j * 64 + 64 <= S) {
 #pragma unroll
       for (int i = 0; i < C::NCH; ++i) {
+        if (C::RAGGED && !st_on[i]) continue;
         kreg[i] = *(const u32x4*)(kb + g_off[i]);
         vreg[i] = *(const u32x4*)(vb + g_off[i]);
       }
     } else {  // tail tile: rows beyond S - 1 re-read the last key (their scores are masked below)
 #pragma unroll
       for (int i = 0; i < C::NCH; ++i) {
+        if (C::RAGGED && !st_on[i]) continue;
         const int kl = min(st_kl[i], S - 1 - j * 64);
         const unsigned off = (unsigned)kl * row_bytes + (g_off[i] - (unsigned)st_kl[i] * row_bytes);
         kreg[i] = *(const u32x4*)(kb + off);
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
   };
 #define DK2_STORE_TILE(BUF)                                                            \
   _Pragma("unroll") for (int i = 0; i < C::NCH; ++i) {                                 \
+    if (C::RAGGED && !st_on[i]) continue;                                              \
     *(__attribute__((address_space(3))) u32x4*)(lds + K_OFF + (BUF) * C::TILE_BYTES + ks_off[i]) = kreg[i]; \
     *(__attribute__((address_space(3))) u32x4*)(lds + V_OFF + (BUF) * C::TILE_BYTES + vs_off[i]) = vreg[i]; \
   }
@@ -240,6 +248,10 @@ static int launch_attn2(const AttnParams& p, hipStream_t stream) {
 
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
   DK_REQUIRE((size_t)p.S * p.ld * 2 < (1ull << 32), "attention2: one batch row of QKV must span < 4 GiB");
-  if (p.D == 128) return waves == 8 ? launch_attn2<128, 8>(p, stream) : launch_attn2<128, 4>(p, stream);
+  if (p.D == 128) {
+    if (waves == 8) return launch_attn2<128, 8>(p, stream);
+    if (waves == 7) return launch_attn2<128, 7>(p, stream);
+    return launch_attn2<128, 4>(p, stream);
+  }
   return waves == 8 ? launch_attn2<64, 8>(p, stream) : launch_attn2<64, 4>(p, stream);
 }
