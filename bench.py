@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="dk_tune_set knob for A/B runs, e.g. --tune gemm_sched=0 (default kernels otherwise)")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,6 +120,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     lib = _lib.load()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(lib.dk_tune_set(k.encode(), int(v)), "dk_tune_set")
 
     if args.workload == "flux-schnell-1024":
         cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"

@@ -259,9 +259,13 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
       DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
       return dk_launch_gemm256v2(p, nullptr, true, stream);
     }
-    if (g_dk_gemm_mode == 6) {
+    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 8) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2)
       DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
-      return dk_launch_gemm256v2(p, nullptr, false, stream);
+      const int saved = g_dk_v2_sched;
+      g_dk_v2_sched = g_dk_gemm_mode - 6;
+      const int rc = dk_launch_gemm256v2(p, nullptr, false, stream);
+      g_dk_v2_sched = saved;
+      return rc;
     }
     if (g_dk_gemm_mode >= 0 && g_dk_gemm_mode < 128) return dk_launch_gemm256(p, g_dk_gemm_mode, stream);
     // automatic choice (kernel lab, profiles/r01_gemm_lab_v2.log): the second-generation 256^2 kernel wins

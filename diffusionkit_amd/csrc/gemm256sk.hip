@@ -65,7 +65,11 @@ __device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r
 // stream of a double block next to its image stream: mmdit.py:568-675 runs the same Linear shapes on
 // both).  The 12 + 192 tiles of the two streams then share one wave of the 256 CUs instead of the
 // text stream running alone on 48 small tiles.
-template <bool STREAMK>
+// SCHED 0: the 8 DMA instructions of a K-tile are issued together after the tile barrier.
+// SCHED 1: they are spread, one in front of every second MFMA, over the two k-steps that follow the
+// barrier, and the two wave groups of a SIMD (wm = 0 / 1) place them on opposite MFMA slots, so that
+// while one wave is busy issuing a global_load_lds (~100 cycles) its partner keeps the MFMA pipe fed.
+template <bool STREAMK, int SCHED>
 __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, SkArgs sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
@@ -141,6 +145,17 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
         }
     };
 
+    auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
+      const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
+      const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
+      if (op == 0)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA + hh * a128 + j * a8 + (size_t)i * (BK * 2) + la[j]),
+                                         (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW + hh * w128 + j * w8 + (size_t)i * (BK * 2) + lw[j]),
+                                         (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, 0, 0);
+    };
+
     f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -171,7 +186,79 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)         \
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf##SET[ni], xf##SET[mi], acc[ni][mi], 0, 0, 0); \
   } while (0)
-    {
+// 8 MFMAs with NG DMA pieces (TILE, G0..G0+NG-1) in front of MFMA slots PH, PH+2, ... when ON
+#define DK_MMG(SET, TILE, G0, NG, PH, ON)                                                                       \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                                          \
+      if ((ON) && e_ >= (PH) && ((e_ - (PH)) & 1) == 0 && ((e_ - (PH)) >> 1) < (NG))                            \
+        issue_piece((TILE), (G0) + ((e_ - (PH)) >> 1));                                                         \
+      acc[e_ >> 2][e_ & 3] =                                                                                    \
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf##SET[e_ >> 2], xf##SET[e_ & 3], acc[e_ >> 2][e_ & 3], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+  } while (0)
+#define DK_LOOP_SCHED1(PH, N3, N0, N1)                                                                          \
+  for (int i = 0; i < nseg; ++i) {                                                                              \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                     \
+    const bool on1 = i >= 1 && i + 1 < nseg; /* second half of tile i+1 (first half went out in S3 of i-1) */    \
+    DK_RD(1, bo, 1);                                                                                            \
+    DK_WAIT(6, 0);                                                                                              \
+    DK_MMG(0, i + 1, N3, N0, PH, on1);                                                                          \
+    DK_RD(0, bo, 2);                                                                                            \
+    DK_WAIT(6, 1);                                                                                              \
+    DK_MMG(1, i + 1, N3 + N0, N1, PH, on1);                                                                     \
+    DK_RD(1, bo, 3);                                                                                            \
+    DK_WAIT(6, 0);                                                                                              \
+    DK_MM(0);                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"                                                                \
+                 : "+v"(wf1[0]), "+v"(wf1[1]), "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])           \
+                 :                                                                                              \
+                 : "memory");                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                               \
+    asm volatile("" ::: "memory");                                                                              \
+    if (STREAMK && publish_pending) {                                                                           \
+      if (tid == 0) __hip_atomic_store(sk.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+      publish_pending = false;                                                                                  \
+    }                                                                                                           \
+    if (i + 1 < nseg) DK_RD(0, bo ^ KT_BYTES, 0);                                                               \
+    DK_MMG(1, i + 2, 0, N3, PH, i + 2 < nseg);                                                                  \
+  }
+    if (SCHED >= 1) {
+      bf16x8 wf0[2], xf0[4], wf1[2], xf1[4];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_tile(0);
+      if (nseg > 1) {
+        issue_tile(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not
+      //  be live across a compiler-visible branch -- hipcc spilled it right after the ds_read, before the data
+      //  had landed, and the wm = 1 waves computed k-step 0 of every tile from garbage)
+      if (SCHED == 1) {  // 4 pieces behind the barrier (S3), 4 in the next k-step (S0)
+        if (wm == 0) {
+          DK_RD(0, 0u, 0);
+          DK_LOOP_SCHED1(0, 4, 4, 0)
+        } else {
+          DK_RD(0, 0u, 0);
+          DK_LOOP_SCHED1(1, 4, 4, 0)
+        }
+      } else {  // SCHED 2: 3 + 3 + 2 over S3, S0, S1
+        if (wm == 0) {
+          DK_RD(0, 0u, 0);
+          DK_LOOP_SCHED1(0, 3, 3, 2)
+        } else {
+          DK_RD(0, 0u, 0);
+          DK_LOOP_SCHED1(1, 3, 3, 2)
+        }
+      }
+    } else {
       bf16x8 wf0[2], xf0[4], wf1[2], xf1[4];
       // every wave has finished the tail of the previous segment (it reads the ring region)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -220,6 +307,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
 #undef DK_RD
 #undef DK_WAIT
 #undef DK_MM
+#undef DK_MMG
+#undef DK_LOOP_SCHED1
 
     // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
     // All waves passed the last loop barrier after their final ds_read, so the ring is free.
@@ -345,6 +434,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
   }
 }
 
+int g_dk_v2_sched = 1;  // dk_tune_set("gemm_sched", v): DMA issue schedule of the v2 kernel (0 grouped, 1 interleaved anti-phase)
+
 bool dk_gemm256v2_eligible(const GemmParams& p) {
   auto seg_ok = [&](int len) { return len >= p.M || len % 256 == 0; };
   return !p.conv && p.n_split % 256 == 0 && (p.n_split == 0 || (p.C2 != nullptr && p.ldc2 % 4 == 0)) && p.M % 256 == 0 && p.N % 256 == 0 && p.K % BK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 4 == 0 &&
@@ -363,8 +454,10 @@ int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk,
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     DK_CHECK_HIP(hipGetDevice(&dev));
     DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -392,9 +485,13 @@ int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk,
   dk_prof_begin(0, work, stream);
   const GemmParams& pb = p2 ? *p2 : p;
   if (streamk)
-    hipLaunchKernelGGL(dk_gemm256v2_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
+    hipLaunchKernelGGL((dk_gemm256v2_kernel<true, 0>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
+  else if (g_dk_v2_sched == 1)
+    hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 1>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
+  else if (g_dk_v2_sched == 2)
+    hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 2>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   else
-    hipLaunchKernelGGL(dk_gemm256v2_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
+    hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 0>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

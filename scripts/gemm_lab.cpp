@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  if (getenv("LAB_SCHED")) dk_tune_set("gemm_sched", atoi(getenv("LAB_SCHED")));
   void* ws = nullptr;
   const size_t ws_bytes = dk_gemm_workspace_bytes();
   CK(hipMalloc(&ws, ws_bytes));
