@@ -1,0 +1,276 @@
+"""Checkpoint loader: BFL FLUX.1 / Stability SD3 safetensors -> the reference's module-tree names.
+
+SURVEY.md §8(f) row f1.  The reference remaps checkpoint keys with chains of ``str.replace`` over the
+whole state dict (python/src/diffusionkit/mlx/model_io.py:130-311 FLUX, :314-408 SD3, :411-486 VAE
+decoder).  Here the same mapping is an explicit table of (pattern -> target) rules, applied once per
+key, plus the four tensor transformations the reference performs:
+
+  * fused ``qkv`` projections are split into q / k / v (:141-153, :361-374); ``k_proj.bias`` does not
+    exist in the reference module (mmdit.py:820-821) and is dropped (:389-390; FLUX drops it in
+    ``model.update``);
+  * FLUX single blocks: ``linear1`` -> q, k, v, fc1 (:224-252); ``linear2`` -> o_proj | fc2 along the
+    input axis, its bias becomes o_proj's (the fc2 copy is zeroed on every call, mmdit.py:741-742:
+    quirk Q8, so only one bias is kept);
+  * conv weights OIHW -> OHWI (:398-400, :455-484), 1x1 convs (VAE attention q/k/v/proj_out,
+    nin_shortcut) -> Linear weights;
+  * SD3 ``pos_embed`` [1, T, h] -> ``x_pos_embedder.pos_embed.weight`` [T, h] (:392-396).
+
+The result is the dict ``diffusionkit_amd.weights.pack_mmdit`` / ``pack_vae`` consume, i.e. exactly
+what ``synth_mmdit_weights`` / ``synth_vae_weights`` produce for the benchmarks.  FLUX.1-dev's
+``guidance_in`` is ignored, as in the reference (quirk Q7).
+"""
+from __future__ import annotations
+
+import re
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from .config import MMDiTConfig, VAEDecoderConfig
+
+Tensor = torch.Tensor
+StateDict = Dict[str, Tensor]
+
+
+class CheckpointError(ValueError):
+    pass
+
+
+def load_safetensors(path: str) -> StateDict:
+    from safetensors.torch import load_file
+    return load_file(path, device="cpu")
+
+
+# ---------------------------------------------------------------------------------------------
+# FLUX.1 (Black Forest Labs key layout)
+# ---------------------------------------------------------------------------------------------
+_FLUX_STREAM = {"img": "image_transformer_block", "txt": "text_transformer_block"}
+_FLUX_TOP = {
+    "img_in": "x_embedder.proj", "txt_in": "context_embedder",
+    "time_in.in_layer": "t_embedder.mlp.layers.0", "time_in.out_layer": "t_embedder.mlp.layers.2",
+    "vector_in.in_layer": "y_embedder.mlp.layers.0", "vector_in.out_layer": "y_embedder.mlp.layers.2",
+    "final_layer.linear": "final_layer.linear", "final_layer.adaLN_modulation.1": "final_layer.adaLN_modulation.layers.1",
+}
+
+
+def flux_checkpoint_to_reference(sd: StateDict, cfg: MMDiTConfig) -> StateDict:
+    """BFL ``flux1-{schnell,dev}.safetensors`` keys -> reference MMDiT names."""
+    h, r = cfg.hidden_size, cfg.mlp_ratio
+    out: StateDict = {}
+    used = set()
+
+    def take(k):
+        used.add(k)
+        return sd[k]
+
+    for k in sd:
+        m = re.fullmatch(r"(.+)\.(weight|bias)", k)
+        stem, leaf = (m.group(1), m.group(2)) if m else (k, "")
+        if stem in _FLUX_TOP:
+            out[f"{_FLUX_TOP[stem]}.{leaf}"] = take(k)
+            continue
+        if stem.startswith("guidance_in."):  # FLUX.1-dev guidance embedding: unused by the reference (Q7)
+            used.add(k)
+            continue
+        m = re.fullmatch(r"double_blocks\.(\d+)\.(img|txt)_attn\.norm\.(query|key)_norm\.scale", k)
+        if m:
+            base = f"multimodal_transformer_blocks.{m.group(1)}.{_FLUX_STREAM[m.group(2)]}"
+            out[f"{base}.qk_norm.{m.group(3)[0]}_norm.weight"] = take(k)
+            continue
+        m = re.fullmatch(r"single_blocks\.(\d+)\.norm\.(query|key)_norm\.scale", k)
+        if m:
+            out[f"unified_transformer_blocks.{m.group(1)}.transformer_block.qk_norm.{m.group(2)[0]}_norm.weight"] = take(k)
+            continue
+        m = re.fullmatch(r"double_blocks\.(\d+)\.(img|txt)_(.+)", stem)
+        if m:
+            base = f"multimodal_transformer_blocks.{m.group(1)}.{_FLUX_STREAM[m.group(2)]}"
+            part = m.group(3)
+            t = take(k)
+            if part == "mod.lin":
+                out[f"{base}.adaLN_modulation.layers.1.{leaf}"] = t
+            elif part == "attn.qkv":
+                q, kk, v = torch.chunk(t, 3, dim=0)
+                out[f"{base}.attn.q_proj.{leaf}"] = q
+                out[f"{base}.attn.v_proj.{leaf}"] = v
+                if leaf == "weight":
+                    out[f"{base}.attn.k_proj.weight"] = kk
+            elif part == "attn.proj":
+                out[f"{base}.attn.o_proj.{leaf}"] = t
+            elif part == "mlp.0":
+                out[f"{base}.mlp.fc1.{leaf}"] = t
+            elif part == "mlp.2":
+                out[f"{base}.mlp.fc2.{leaf}"] = t
+            else:
+                raise CheckpointError(f"unknown FLUX double-block tensor: {k}")
+            continue
+        m = re.fullmatch(r"single_blocks\.(\d+)\.(linear1|linear2|modulation\.lin)", stem)
+        if m:
+            base = f"unified_transformer_blocks.{m.group(1)}.transformer_block"
+            t = take(k)
+            if m.group(2) == "modulation.lin":
+                out[f"{base}.adaLN_modulation.layers.1.{leaf}"] = t
+            elif m.group(2) == "linear1":
+                q, kk, v, fc1 = torch.split(t, [h, h, h, r * h], dim=0)
+                out[f"{base}.attn.q_proj.{leaf}"] = q
+                out[f"{base}.attn.v_proj.{leaf}"] = v
+                if leaf == "weight":
+                    out[f"{base}.attn.k_proj.weight"] = kk
+                out[f"{base}.mlp.fc1.{leaf}"] = fc1
+            else:  # linear2 over [attention | gelu(fc1)]
+                if leaf == "weight":
+                    o, fc2 = torch.split(t, [h, r * h], dim=1)
+                    out[f"{base}.attn.o_proj.weight"] = o.contiguous()
+                    out[f"{base}.mlp.fc2.weight"] = fc2.contiguous()
+                else:
+                    out[f"{base}.attn.o_proj.bias"] = t  # the fc2 copy is zeroed at run time (Q8)
+            continue
+        raise CheckpointError(f"unknown FLUX checkpoint key: {k}")
+    w = out.get("x_embedder.proj.weight")
+    if w is None:
+        raise CheckpointError("img_in.weight missing")
+    out["x_embedder.proj.weight"] = w.reshape(w.shape[0], 1, 1, w.shape[1])  # Linear 64->h as a 1x1 conv (:306-308)
+    _check_mmdit_complete(out, cfg)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# SD3 / SD3.5 (Stability key layout, prefix "model.diffusion_model.")
+# ---------------------------------------------------------------------------------------------
+_SD3_STREAM = {"x_block": "image_transformer_block", "context_block": "text_transformer_block"}
+
+
+def sd3_checkpoint_to_reference(sd: StateDict, cfg: MMDiTConfig, prefix: str = "model.diffusion_model.") -> StateDict:
+    """``sd3_medium.safetensors``-style keys -> reference MMDiT names (VAE / teacher tensors are skipped)."""
+    out: StateDict = {}
+    for k0, t in sd.items():
+        if not k0.startswith(prefix):
+            continue  # first_stage_model.*, text encoders, teacher_model.* ...
+        k = k0[len(prefix):]
+        if k == "pos_embed":
+            out["x_pos_embedder.pos_embed.weight"] = t[0]
+            continue
+        m = re.fullmatch(r"(.+)\.(weight|bias)", k)
+        if not m:
+            raise CheckpointError(f"unknown SD3 checkpoint key: {k0}")
+        stem, leaf = m.group(1), m.group(2)
+        if stem == "x_embedder.proj":
+            out[f"x_embedder.proj.{leaf}"] = t.permute(0, 2, 3, 1).contiguous() if leaf == "weight" else t
+        elif stem == "context_embedder" or stem == "final_layer.linear":
+            out[f"{stem}.{leaf}"] = t
+        elif (m3 := re.fullmatch(r"([ty]_embedder)\.mlp\.([02])", stem)):
+            out[f"{m3.group(1)}.mlp.layers.{m3.group(2)}.{leaf}"] = t
+        elif stem == "final_layer.adaLN_modulation.1":
+            out[f"final_layer.adaLN_modulation.layers.1.{leaf}"] = t
+        else:
+            m2 = re.fullmatch(r"joint_blocks\.(\d+)\.(x_block|context_block)\.(.+)", stem)
+            if not m2:
+                raise CheckpointError(f"unknown SD3 checkpoint key: {k0}")
+            base = f"multimodal_transformer_blocks.{m2.group(1)}.{_SD3_STREAM[m2.group(2)]}"
+            part = m2.group(3)
+            if part == "attn.qkv":
+                q, kk, v = torch.chunk(t, 3, dim=0)
+                out[f"{base}.attn.q_proj.{leaf}"] = q
+                out[f"{base}.attn.v_proj.{leaf}"] = v
+                if leaf == "weight":
+                    out[f"{base}.attn.k_proj.weight"] = kk
+            elif part == "attn.proj":
+                out[f"{base}.attn.o_proj.{leaf}"] = t
+            elif part in ("attn.ln_q", "attn.ln_k"):
+                out[f"{base}.qk_norm.{part[-1]}_norm.{leaf}"] = t
+            elif part in ("mlp.fc1", "mlp.fc2"):
+                out[f"{base}.{part}.{leaf}"] = t
+            elif part == "adaLN_modulation.1":
+                out[f"{base}.adaLN_modulation.layers.1.{leaf}"] = t
+            else:
+                raise CheckpointError(f"unknown SD3 block tensor: {k0}")
+    _check_mmdit_complete(out, cfg)
+    return out
+
+
+def _check_mmdit_complete(out: StateDict, cfg: MMDiTConfig) -> None:
+    """Every tensor pack_mmdit needs must be present with the right shape (fail loudly, name the key)."""
+    from .weights import mmdit_weight_shapes
+    want = mmdit_weight_shapes(cfg)
+    missing = sorted(set(want) - set(out))
+    if missing:
+        raise CheckpointError(f"checkpoint lacks {len(missing)} tensors, first: {missing[:3]}")
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise CheckpointError(f"{k}: shape {tuple(out[k].shape)} != expected {shp}")
+    extra = sorted(set(out) - set(want))
+    if extra:
+        raise CheckpointError(f"checkpoint produced unexpected tensors: {extra[:3]}")
+
+
+# ---------------------------------------------------------------------------------------------
+# VAE decoder (CompVis layout; prefix "first_stage_model.decoder." in SD3 files, "decoder." in ae.safetensors)
+# ---------------------------------------------------------------------------------------------
+def vae_decoder_checkpoint_to_reference(sd: StateDict, cfg: VAEDecoderConfig, prefix: str = "decoder.") -> StateDict:
+    out: StateDict = {}
+
+    def conv(t):  # OIHW -> OHWI
+        return t.permute(0, 2, 3, 1).contiguous()
+
+    for k0, t in sd.items():
+        if not k0.startswith(prefix):
+            continue  # encoder.*, model.diffusion_model.*, text encoders ...
+        k = k0[len(prefix):]
+        m = re.fullmatch(r"(.+)\.(weight|bias)", k)
+        if not m:
+            continue
+        stem, leaf = m.group(1), m.group(2)
+        w = leaf == "weight"
+        if stem in ("conv_in", "conv_out"):
+            out[f"{stem}.{leaf}"] = conv(t) if w else t
+        elif stem == "norm_out":
+            out[f"conv_norm_out.{leaf}"] = t
+        elif (m2 := re.fullmatch(r"mid\.block_([12])\.(norm1|conv1|norm2|conv2)", stem)):
+            idx = 0 if m2.group(1) == "1" else 2
+            out[f"mid_blocks.{idx}.{m2.group(2)}.{leaf}"] = conv(t) if (w and "conv" in m2.group(2)) else t
+        elif (m2 := re.fullmatch(r"mid\.attn_1\.(norm|q|k|v|proj_out)", stem)):
+            name = {"norm": "group_norm", "q": "query_proj", "k": "key_proj", "v": "value_proj", "proj_out": "out_proj"}[m2.group(1)]
+            out[f"mid_blocks.1.{name}.{leaf}"] = t[:, :, 0, 0].contiguous() if (w and name != "group_norm") else t
+        elif (m2 := re.fullmatch(r"up\.(\d+)\.block\.(\d+)\.(norm1|conv1|norm2|conv2|nin_shortcut)", stem)):
+            base = f"up_blocks.{m2.group(1)}.resnets.{m2.group(2)}"
+            part = m2.group(3)
+            if part == "nin_shortcut":
+                out[f"{base}.conv_shortcut.{leaf}"] = t[:, :, 0, 0].contiguous() if w else t
+            else:
+                out[f"{base}.{part}.{leaf}"] = conv(t) if (w and "conv" in part) else t
+        elif (m2 := re.fullmatch(r"up\.(\d+)\.upsample\.conv", stem)):
+            out[f"up_blocks.{m2.group(1)}.upsample.{leaf}"] = conv(t) if w else t
+        else:
+            raise CheckpointError(f"unknown VAE decoder key: {k0}")
+    from .weights import vae_weight_shapes
+    want = vae_weight_shapes(cfg)
+    missing = sorted(set(want) - set(out))
+    if missing:
+        raise CheckpointError(f"VAE checkpoint lacks {len(missing)} tensors, first: {missing[:3]}")
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise CheckpointError(f"{k}: shape {tuple(out[k].shape)} != expected {shp}")
+    return {k: out[k] for k in want}
+
+
+# ---------------------------------------------------------------------------------------------
+# entry points used by the pipelines (local_ckpt={"mmdit": path_or_dict, "vae_decoder": path_or_dict})
+# ---------------------------------------------------------------------------------------------
+def load_mmdit_checkpoint(src, cfg: MMDiTConfig) -> StateDict:
+    """``src``: a dict already in reference names, a raw checkpoint dict, or a .safetensors path."""
+    sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if any(k.startswith("multimodal_transformer_blocks.") for k in sd):
+        return sd  # already remapped
+    if any(k.startswith("double_blocks.") for k in sd):
+        return flux_checkpoint_to_reference(sd, cfg)
+    for pre in ("model.diffusion_model.", ""):
+        if any(k.startswith(pre + "joint_blocks.") for k in sd):
+            return sd3_checkpoint_to_reference(sd, cfg, prefix=pre)
+    raise CheckpointError("unrecognised MMDiT checkpoint layout (neither BFL FLUX nor Stability SD3 keys)")
+
+
+def load_vae_decoder_checkpoint(src, cfg: VAEDecoderConfig) -> StateDict:
+    sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if any(k.startswith("up_blocks.") for k in sd):
+        return sd
+    pre = "first_stage_model.decoder." if any(k.startswith("first_stage_model.decoder.") for k in sd) else "decoder."
+    return vae_decoder_checkpoint_to_reference(sd, cfg, prefix=pre)

@@ -132,7 +132,9 @@ class DiffusionPipeline:
             self.mmdit = MMDiTEngine(cfg, self._packed_weights["mmdit"])
             return
         if isinstance(self.local_ckpt, dict) and "mmdit" in self.local_ckpt:
-            named = dict(self.local_ckpt["mmdit"])
+            # a .safetensors path or a state dict, in BFL FLUX / Stability SD3 / reference key layout
+            from .model_io import load_mmdit_checkpoint
+            named = dict(load_mmdit_checkpoint(self.local_ckpt["mmdit"], cfg))
         else:
             named = synth_mmdit_weights(cfg, seed=self.weights_seed, device=self._synth_device(cfg.param_count()))
         self.mmdit = MMDiTEngine(cfg, pack_mmdit(cfg, named, self.device, consume=True))
@@ -150,7 +152,8 @@ class DiffusionPipeline:
             self.decoder = VAEDecoderEngine(self.vae_config, self._packed_weights["vae_decoder"])
         if not hasattr(self, "decoder"):
             if isinstance(self.local_ckpt, dict) and "vae_decoder" in self.local_ckpt:
-                named = self.local_ckpt["vae_decoder"]
+                from .model_io import load_vae_decoder_checkpoint
+                named = load_vae_decoder_checkpoint(self.local_ckpt["vae_decoder"], self.vae_config)
             else:
                 named = synth_vae_weights(self.vae_config, seed=self.weights_seed + 1, device="cpu")
             self.decoder = VAEDecoderEngine(self.vae_config, pack_vae(self.vae_config, named, self.device))

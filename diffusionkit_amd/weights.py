@@ -32,12 +32,20 @@ def _gen(device, seed):
 
 
 class _Init:
-    def __init__(self, device, seed, dtype):
-        self.device, self.dtype = torch.device(device), dtype
-        self.g = _gen(self.device, seed)
+    """Seeded initialiser; with ``shapes_only`` it records ``name -> shape`` instead of drawing tensors
+    (the checkpoint loader validates against that table)."""
+
+    def __init__(self, device, seed, dtype, shapes_only=False):
+        self.shapes_only = shapes_only
         self.out: Dict[str, Tensor] = {}
+        if not shapes_only:
+            self.device, self.dtype = torch.device(device), dtype
+            self.g = _gen(self.device, seed)
 
     def normal(self, name, shape, std=0.02, mean=0.0):
+        if self.shapes_only:
+            self.out[name] = tuple(shape)
+            return
         t = torch.randn(*shape, generator=self.g, device=self.device, dtype=torch.float32) * std + mean
         self.out[name] = t.to(self.dtype)
 
@@ -47,9 +55,18 @@ class _Init:
             self.normal(prefix + ".bias", (out_f,))
 
 
-def synth_mmdit_weights(cfg: MMDiTConfig, seed: int = 1234, device="cpu", dtype=torch.bfloat16) -> Dict[str, Tensor]:
+def mmdit_weight_shapes(cfg: MMDiTConfig) -> Dict[str, tuple]:
+    """name -> shape of every tensor of the reference MMDiT module tree for ``cfg``."""
+    return synth_mmdit_weights(cfg, shapes_only=True)
+
+
+def vae_weight_shapes(cfg: VAEDecoderConfig) -> Dict[str, tuple]:
+    return synth_vae_weights(cfg, shapes_only=True)
+
+
+def synth_mmdit_weights(cfg: MMDiTConfig, seed: int = 1234, device="cpu", dtype=torch.bfloat16, shapes_only=False) -> Dict[str, Tensor]:
     """Random weights keyed like the reference MMDiT module tree (mmdit.py:22-75)."""
-    I = _Init(device, seed, dtype)
+    I = _Init(device, seed, dtype, shapes_only)
     h, D, r = cfg.hidden_size, cfg.head_dim, cfg.mlp_ratio
     p = cfg.patch_size
     if cfg.patchify_via_reshape:
@@ -88,9 +105,9 @@ def synth_mmdit_weights(cfg: MMDiTConfig, seed: int = 1234, device="cpu", dtype=
     return I.out
 
 
-def synth_vae_weights(cfg: VAEDecoderConfig, seed: int = 4321, device="cpu", dtype=torch.bfloat16) -> Dict[str, Tensor]:
+def synth_vae_weights(cfg: VAEDecoderConfig, seed: int = 4321, device="cpu", dtype=torch.bfloat16, shapes_only=False) -> Dict[str, Tensor]:
     """Random weights keyed like the reference VAEDecoder module tree (vae.py:336-384)."""
-    I = _Init(device, seed, dtype)
+    I = _Init(device, seed, dtype, shapes_only)
 
     def conv(prefix, o, i):
         I.normal(prefix + ".weight", (o, 3, 3, i))

@@ -207,6 +207,28 @@ def test_generate_image_api(dev):
     assert fl.shape == (1, 64, 64, 3) and float(fl.min()) >= 0.0 and float(fl.max()) <= 1.0
 
 
+def test_pipeline_from_bfl_checkpoint_file(dev, tmp_path):
+    """local_ckpt pointing at safetensors files in the upstream key layouts (BFL FLUX transformer, CompVis
+    VAE decoder) gives bit-identical latents / images to the same weights passed as a reference-named dict."""
+    import os
+    from safetensors.torch import save_file
+    from diffusionkit_amd.pipeline import FluxPipeline
+    from tests.test_model_io import to_bfl_flux, to_compvis_vae
+    cfg, vcfg = tiny_flux(), tiny_vae()
+    w, vw = synth_mmdit_weights(cfg, seed=21), synth_vae_weights(vcfg, seed=22)
+    fp, vp = os.path.join(tmp_path, "flux.safetensors"), os.path.join(tmp_path, "ae.safetensors")
+    save_file(to_bfl_flux(w, cfg), fp)
+    save_file(to_compvis_vae(vw, vcfg), vp)
+    text, pooled = randn(1, 16, cfg.token_level_text_embed_dim, seed=7).to(dev, BF), randn(1, cfg.pooled_text_embed_dim, seed=8).to(dev, BF)
+    outs = []
+    for ck in ({"mmdit": fp, "vae_decoder": vp}, {"mmdit": w, "vae_decoder": vw}):
+        pipe = FluxPipeline(w16=True, a16=True, local_ckpt=ck, mmdit_config=cfg, vae_config=vcfg, device=dev, text_len=16)
+        lat, _ = pipe.denoise_latents(text, pooled, num_steps=2, latent_size=(8, 8), seed=4)
+        _, u8, _ = pipe.decoder.decode(lat)
+        outs.append((lat.clone(), u8.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_multi_seed_batch_equals_single(dev):
     """Data-parallel shards hand each rank a list of seeds: batching them must equal one-by-one."""
     from diffusionkit_amd.pipeline import FluxPipeline
