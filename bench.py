@@ -218,7 +218,7 @@ def main():
         if os.path.exists(pmc):  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         roofline = {
-            "bound": "mfma", "kernel": "dk_gemm256v2_kernel<false> (bf16 MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            "bound": "mfma", "kernel": "dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "flops_per_launch": work / max(n, 1),

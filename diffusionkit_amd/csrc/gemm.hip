@@ -259,7 +259,7 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
       DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
       return dk_launch_gemm256v2(p, nullptr, true, stream);
     }
-    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 8) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2)
+    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 9) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2), 9: 16x16x32 MFMA K loop
       DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
       const int saved = g_dk_v2_sched;
       g_dk_v2_sched = g_dk_gemm_mode - 6;

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
   }
 }
 
-int g_dk_v2_sched = 1;  // dk_tune_set("gemm_sched", v): DMA issue schedule of the v2 kernel (0 grouped, 1 interleaved anti-phase)
+int g_dk_v2_sched = 3;  // dk_tune_set("gemm_sched", v): 0 grouped DMA issue, 1 / 2 interleaved anti-phase (32x32x16 MFMA), 3 = gemm256v3.hip (16x16x32 MFMA, default)
 
 bool dk_gemm256v2_eligible(const GemmParams& p) {
   auto seg_ok = [&](int len) { return len >= p.M || len % 256 == 0; };
@@ -484,7 +484,9 @@ int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk,
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
   const GemmParams& pb = p2 ? *p2 : p;
-  if (streamk)
+  if (!streamk && g_dk_v2_sched == 3)
+    dk_launch_gemm256v3_raw(p, pb, tiles_a, tiles_b, stream);
+  else if (streamk)
     hipLaunchKernelGGL((dk_gemm256v2_kernel<true, 0>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   else if (g_dk_v2_sched == 1)
     hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 1>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);

@@ -1,0 +1,284 @@
+// 256 x 256 x 64 bf16 MFMA GEMM, third generation: the second-generation kernel (gemm256sk.hip, tile-parallel
+// form) with the K loop rebuilt on v_mfma_f32_16x16x32_bf16.  Same contract, same eligibility rule, same
+// grouped (two-problem) launch and column split; nn.Linear call sites python/src/diffusionkit/mlx/mmdit.py
+// :821-832 and the fused linear1 / linear2 of the single-stream blocks (:693-751).
+//
+// Why: the chip is power-limited on real (random) bf16 data, and the 16x16x32 instruction does the same FLOPs
+// for less power than 32x32x16 -- scripts/mfma_probe.hip measures 2.21-2.24 PFLOP/s against 1.90-1.93 PFLOP/s
+// for the same operand fragments (both reach 2.49 PFLOP/s on zeros).
+//
+// K loop: 8 waves (2 x 4), wave tile 128 (m) x 64 (n); per K = 32 slice the wave needs 4 W fragments and
+// 8 A fragments (ds_read_b128 each: row = base + (lane & 15), 16-byte chunk = 4 * kk + (lane >> 4)) for
+// 32 MFMAs.  A K-tile is 4 steps of 16 MFMAs:  (kk0, m 0-63), (kk0, m 64-127), (kk1, m 0-63), (kk1, m 64-127),
+// with two W register sets and two A register sets reloaded one step ahead (inline-asm ds_read_b128,
+// hand-counted s_waitcnt lgkmcnt), the tile barrier between steps 2 and 3, and the 8 global_load_lds
+// instructions of a K-tile spread over steps 3 and 0, one in front of every fourth MFMA, on opposite slots for
+// the two wave groups of a SIMD.
+//
+// C / D layout of the swapped-operand MFMA (A-operand = W fragment, B-operand = activation fragment):
+// lane holds output row m = mf*16 + (lane & 15), columns n = nf*16 + 4*(lane >> 4) + {0..3}.
+#include "dk_kernels.h"
+
+#define T256 256
+#define BK 64
+#define HALF_BYTES (128 * BK * 2)
+#define KT_BYTES (4 * HALF_BYTES)
+#define LDS_BYTES (2 * KT_BYTES)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
+
+__global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const int nk = pa.K / BK;
+  const int G = tiles_a + tiles_b;
+  int tile;  // XCD-contiguous workgroup index: neighbouring tiles share an L2
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qq = G >> 3, r = G & 7;
+    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+  }
+  const bool second = tile >= tiles_a;
+  const GemmParams& p = second ? pb : pa;
+  const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
+  const int nbm = p.M / T256, nbn = p.N / T256;
+
+  // ---- lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), chunk 4*kk + q ----
+  unsigned offk[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) offk[kk] = (unsigned)(l15 * 128 + (((kk * 4 + q) ^ (l15 >> 1)) << 4));
+  const unsigned sA = wm * HALF_BYTES;
+  const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
+
+  const int srow = lane >> 3;
+  unsigned la[2], lw[2];  // lane part of the A / W source byte offset for DMA instruction j
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
+    la[j] = ((unsigned)srow * (unsigned)p.lda + chunk * 8) * 2u;
+    lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
+  }
+  const int GROUP = 4;
+  const int tpg = GROUP * nbn;
+  const int g = tl / tpg;
+  const int first_m = g * GROUP;
+  const int gsz = min(nbm - first_m, GROUP);
+  const int tm = first_m + (tl % tpg) % gsz;
+  const int tn = (tl % tpg) / gsz;
+  const int m0 = tm * T256, n0 = tn * T256;
+
+  // tile-uniform source bases (bytes): rows m0 + hh*128 + wave*16 + j*8 (+ srow in the lane part)
+  const size_t physA0 = (size_t)((m0 / p.a_seg_len) * p.a_seg_stride + (m0 % p.a_seg_len));
+  const char* gA = (const char*)p.A + (physA0 + wave * 16) * (size_t)p.lda * 2;
+  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2;
+  const size_t a128 = (size_t)128 * p.lda * 2, a8 = (size_t)8 * p.lda * 2;
+  const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
+
+  auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
+    const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
+    const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
+    if (op == 0)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA + hh * a128 + j * a8 + (size_t)i * (BK * 2) + la[j]),
+                                       (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW + hh * w128 + j * w8 + (size_t)i * (BK * 2) + lw[j]),
+                                       (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, 0, 0);
+  };
+  auto issue_tile = [&](int i) {
+#pragma unroll
+    for (int gidx = 0; gidx < 8; ++gidx) issue_piece(i, gidx);
+  };
+
+  f32x4 acc[4][8];  // [nf][mf]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // ---------------- K loop: register-pipelined, hand-counted LDS waits ----------------
+#define DK_LDS_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define DK_RDW(SET, BUFOFF, KK)                    \
+  do {                                             \
+    const unsigned aW_ = offk[KK] + sW + (BUFOFF); \
+    DK_LDS_RD(wf##SET[0], aW_, 0);                 \
+    DK_LDS_RD(wf##SET[1], aW_, 2048);              \
+    DK_LDS_RD(wf##SET[2], aW_, 4096);              \
+    DK_LDS_RD(wf##SET[3], aW_, 6144);              \
+  } while (0)
+#define DK_RDA_LO(SET, BUFOFF, KK)                 \
+  do {                                             \
+    const unsigned aA_ = offk[KK] + sA + (BUFOFF); \
+    DK_LDS_RD(xf##SET[0], aA_, 0);                 \
+    DK_LDS_RD(xf##SET[1], aA_, 2048);              \
+    DK_LDS_RD(xf##SET[2], aA_, 4096);              \
+    DK_LDS_RD(xf##SET[3], aA_, 6144);              \
+  } while (0)
+#define DK_RDA_HI(SET, BUFOFF, KK)                 \
+  do {                                             \
+    const unsigned aA_ = offk[KK] + sA + (BUFOFF); \
+    DK_LDS_RD(xf##SET[0], aA_, 8192);              \
+    DK_LDS_RD(xf##SET[1], aA_, 10240);             \
+    DK_LDS_RD(xf##SET[2], aA_, 12288);             \
+    DK_LDS_RD(xf##SET[3], aA_, 14336);             \
+  } while (0)
+#define DK_WAIT4(N, V) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]))
+#define DK_WAIT8(N, V, U)                  \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" \
+               : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]))
+// 16 MFMAs acc[nf][MB + mf] += W[nf] . A[mf], with NG DMA pieces (TILE, G0 ..) in front of slots PH, PH+4, ... when ON
+#define DK_MMG(WSET, ASET, MB, TILE, G0, NG, PH, ON)                                                              \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                           \
+      if ((NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) & 3) == 0 && ((e_ - (PH)) >> 2) < (NG))                  \
+        issue_piece((TILE), (G0) + ((e_ - (PH)) >> 2));                                                           \
+      acc[e_ >> 2][(MB) + (e_ & 3)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##WSET[e_ >> 2], xf##ASET[e_ & 3], \
+                                                                              acc[e_ >> 2][(MB) + (e_ & 3)], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }                                                                                                             \
+  } while (0)
+#define DK_LOOP(PH)                                                                                            \
+  for (int i = 0; i < nk; ++i) {                                                                               \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                    \
+    const bool on1 = i >= 1 && i + 1 < nk; /* second half of tile i+1 (first half went out in S3 of i-1) */     \
+    DK_RDA_HI(1, bo, 0);                                                                                       \
+    DK_WAIT8(4, wf0, xf0);                                                                                     \
+    DK_MMG(0, 0, 0, i + 1, 4, 4, PH, on1);                                                                     \
+    DK_RDW(1, bo, 1);                                                                                          \
+    DK_RDA_LO(0, bo, 1);                                                                                       \
+    DK_WAIT4(8, xf1);                                                                                          \
+    DK_MMG(0, 1, 4, 0, 0, 0, 0, false);                                                                        \
+    DK_RDA_HI(1, bo, 1);                                                                                       \
+    DK_WAIT8(4, wf1, xf0);                                                                                     \
+    DK_MMG(1, 0, 0, 0, 0, 0, 0, false);                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    asm volatile("" ::: "memory");                                                                             \
+    DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */      \
+    DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */      \
+    DK_MMG(1, 1, 4, i + 2, 0, 4, PH, i + 2 < nk);                                                              \
+  }
+
+  {
+    bf16x8 wf0[4], wf1[4], xf0[4], xf1[4];
+    issue_tile(0);
+    if (nk > 1) {
+      issue_tile(1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not be
+    //  live across a compiler-visible branch, see gemm256sk.hip)
+    if (wm == 0) {
+      DK_RDW(0, 0u, 0);
+      DK_RDA_LO(0, 0u, 0);
+      DK_LOOP(0)
+      DK_WAIT8(0, wf0, xf0);
+    } else {
+      DK_RDW(0, 0u, 0);
+      DK_RDA_LO(0, 0u, 0);
+      DK_LOOP(2)
+      DK_WAIT8(0, wf0, xf0);
+    }
+  }
+#undef DK_LDS_RD
+#undef DK_RDW
+#undef DK_RDA_LO
+#undef DK_RDA_HI
+#undef DK_WAIT4
+#undef DK_WAIT8
+#undef DK_MMG
+#undef DK_LOOP
+
+  // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
+  // All waves passed the last loop barrier after their final ds_read, so the ring is free.
+  const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
+  bf16_t* const Cb = out2 ? p.C2 : p.C;
+  const int ldcb = out2 ? p.ldc2 : p.ldc;
+  const int epi = out2 ? p.epi2 : p.epi;
+  const int ncol0 = out2 ? n0 - p.n_split : n0;
+  const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
+  const size_t physR0 = (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128;
+  const bf16_t* gate_row = p.gate ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
+  const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
+  const int rrow = lane >> 3, rchunk = lane & 7;   // read-back: 8 rows x 8 chunks of 16 B per instruction
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) {
+        const int row = mf * 16 + l15;
+        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ (row & 7)) << 4)) = acc[ni * 2 + nf][mf];
+      }
+    // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
+    const int col = n0 + wn * 64 + ni * 32 + rchunk * 4;      // column of the GEMM (bias, gate, residual)
+    const int ocol = ncol0 + wn * 64 + ni * 32 + rchunk * 4;  // column inside the output it goes to
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gate4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const uint2 bb = *(const uint2*)(p.bias + col);
+      unpack2bf(bb.x, bias4[0], bias4[1]);
+      unpack2bf(bb.y, bias4[2], bias4[3]);
+    }
+    if (epi == DK_EPI_GATE_RES) {
+      const uint2 gg = *(const uint2*)(gate_row + col);
+      unpack2bf(gg.x, gate4[0], gate4[1]);
+      unpack2bf(gg.y, gate4[2], gate4[3]);
+    }
+#pragma unroll 4
+    for (int itr = 0; itr < 16; ++itr) {
+      const int row = itr * 8 + rrow;  // row inside the wave's 128-row block
+      const f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
+      float vv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
+      if (epi == DK_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = gelu_erf_f(vv[e]);
+      } else if (epi == DK_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = silu_f(vv[e]);
+      } else if (epi == DK_EPI_GATE_RES || epi == DK_EPI_RES) {
+        const uint2 rr = *(const uint2*)(p.res + (physR0 + row) * (size_t)p.ldr + col);
+        float r4[4];
+        unpack2bf(rr.x, r4[0], r4[1]);
+        unpack2bf(rr.y, r4[2], r4[3]);
+        if (epi == DK_EPI_GATE_RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = r4[e] + round_bf16(gate4[e] * vv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += r4[e];
+        }
+      }
+      uint2 o2;
+      o2.x = pack2bf(vv[0], vv[1]);
+      o2.y = pack2bf(vv[2], vv[3]);
+      *(uint2*)(Cb + (physC0 + row) * (size_t)ldcb + ocol) = o2;
+    }
+  }
+}
+
+int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dk_gemm256v3_kernel, dim3(tiles_a + tiles_b), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b);
+  return 0;
+}

@@ -92,7 +92,8 @@ def test_gemm_segment_mapping_in_place(dev):
 
 
 GEMM_MODES = {128: "128^2 tiles", 0: "256^2 simple", 1: "256^2 staggered", 5: "256^2 register-pipelined",
-              6: "256^2 v2 (LDS-staged tail)", 3: "256^2 v2 stream-K"}
+              6: "256^2 v2 (LDS-staged tail)", 7: "256^2 v2 interleaved DMA issue", 9: "256^2 v3 (16x16x32 MFMA)",
+              3: "256^2 v2 stream-K"}
 
 
 @pytest.mark.parametrize("mode", sorted(GEMM_MODES))
