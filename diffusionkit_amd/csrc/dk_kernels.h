@@ -50,6 +50,8 @@ extern int g_dk_v2_sched;
 size_t dk_streamk_workspace_bytes();
 bool dk_gemm256v2_eligible(const GemmParams& p);
 int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk, hipStream_t stream);  // gemm256sk.hip
+bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 256 == 0, K % 64 == 0, any M, any row-segment maps
+int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream);  // gemm256v3.hip (16x16x32 MFMA K loop)
 // two problems with the same N, K, epilogue in one launch (image + text stream of a double block); falls
 // back to two launches when the pair is not eligible for the grouped kernel

@@ -259,7 +259,11 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
       DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
       return dk_launch_gemm256v2(p, nullptr, true, stream);
     }
-    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 9) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2), 9: 16x16x32 MFMA K loop
+    if (g_dk_gemm_mode == 9) {  // 16x16x32-MFMA kernel on anything it accepts (ragged M, segment-straddling tiles)
+      DK_REQUIRE(dk_gemm256v3_eligible(p), "gemm256v3 forced but the shape does not allow it");
+      return dk_launch_gemm256v3(p, nullptr, stream);
+    }
+    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 8) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2)
       DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
       const int saved = g_dk_v2_sched;
       g_dk_v2_sched = g_dk_gemm_mode - 6;
@@ -305,12 +309,18 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
   GemmParams a = a_in, b = b_in;
   if (a.ldw <= 0) a.ldw = a.K;
   if (b.ldw <= 0) b.ldw = b.K;
-  const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha;
-  if (g_dk_gemm_mode == -1 && same && dk_gemm256v2_eligible(a) && dk_gemm256v2_eligible(b)) {
-    // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial
-    // extra wave costs more than the small separate launch)
-    const long ta = (long)(a.M / 256) * (a.N / 256), tb = (long)(b.M / 256) * (b.N / 256);
-    if ((ta + 255) / 256 == (ta + tb + 255) / 256) return dk_launch_gemm256v2(a, &b, false, stream);
+  const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha && a.n_split == 0 && b.n_split == 0;
+  if (g_dk_gemm_mode == -1 && same && (a.M >= 1024 || b.M >= 1024)) {
+    // the third-generation kernel takes any M and any row-segment map (a ragged or segment-straddling text stream
+    // next to its image stream); the second-generation one needs both problems tile-aligned
+    const bool v3 = g_dk_v2_sched == 3 && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b);
+    const bool v2 = dk_gemm256v2_eligible(a) && dk_gemm256v2_eligible(b);
+    if (v3 || v2) {
+      // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial
+      // extra wave costs more than the small separate launch)
+      const long ta = (long)((a.M + 255) / 256) * (a.N / 256), tb = (long)((b.M + 255) / 256) * (b.N / 256);
+      if ((ta + 255) / 256 == (ta + tb + 255) / 256) return v3 ? dk_launch_gemm256v3(a, &b, stream) : dk_launch_gemm256v2(a, &b, false, stream);
+    }
   }
   int rc = dk_launch_gemm(a, stream);
   if (rc) return rc;

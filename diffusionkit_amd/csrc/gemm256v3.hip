@@ -1,7 +1,12 @@
 // 256 x 256 x 64 bf16 MFMA GEMM, third generation: the second-generation kernel (gemm256sk.hip, tile-parallel
-// form) with the K loop rebuilt on v_mfma_f32_16x16x32_bf16.  Same contract, same eligibility rule, same
-// grouped (two-problem) launch and column split; nn.Linear call sites python/src/diffusionkit/mlx/mmdit.py
-// :821-832 and the fused linear1 / linear2 of the single-stream blocks (:693-751).
+// form) with the K loop rebuilt on v_mfma_f32_16x16x32_bf16.  Same contract, same grouped (two-problem) launch and
+// column split; nn.Linear call sites python/src/diffusionkit/mlx/mmdit.py:821-832 and the fused linear1 / linear2
+// of the single-stream blocks (:693-751).
+//
+// Shapes: N % 256 == 0 and K % 64 == 0; M is free.  Rows go through the segment maps per lane on the load side
+// (clamped to the last row when M is ragged) and, in the tail, per tile when the tile lies inside one segment
+// (the common case) or per row when it straddles a segment boundary or the end of M -- the text stream of the
+// SD3 double blocks (B = 2 segments of 589 rows, mmdit.py:608-625) rides in the image stream's launch that way.
 //
 // Why: the chip is power-limited on real (random) bf16 data, and the 16x16x32 instruction does the same FLOPs
 // for less power than 32x32x16 -- scripts/mfma_probe.hip measures 2.21-2.24 PFLOP/s against 1.90-1.93 PFLOP/s
@@ -17,6 +22,8 @@
 //
 // C / D layout of the swapped-operand MFMA (A-operand = W fragment, B-operand = activation fragment):
 // lane holds output row m = mf*16 + (lane & 15), columns n = nf*16 + 4*(lane >> 4) + {0..3}.
+#include <type_traits>
+
 #include "dk_kernels.h"
 
 #define T256 256
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const bool second = tile >= tiles_a;
   const GemmParams& p = second ? pb : pa;
   const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
-  const int nbm = p.M / T256, nbn = p.N / T256;
+  const int nbm = (p.M + T256 - 1) / T256, nbn = p.N / T256;
 
   // ---- lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), chunk 4*kk + q ----
   unsigned offk[2];
@@ -59,13 +66,6 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
 
   const int srow = lane >> 3;
-  unsigned la[2], lw[2];  // lane part of the A / W source byte offset for DMA instruction j
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
-    la[j] = ((unsigned)srow * (unsigned)p.lda + chunk * 8) * 2u;
-    lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
-  }
   const int GROUP = 4;
   const int tpg = GROUP * nbn;
   const int g = tl / tpg;
@@ -75,18 +75,29 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const int tn = (tl % tpg) / gsz;
   const int m0 = tm * T256, n0 = tn * T256;
 
-  // tile-uniform source bases (bytes): rows m0 + hh*128 + wave*16 + j*8 (+ srow in the lane part)
-  const size_t physA0 = (size_t)((m0 / p.a_seg_len) * p.a_seg_stride + (m0 % p.a_seg_len));
-  const char* gA = (const char*)p.A + (physA0 + wave * 16) * (size_t)p.lda * 2;
+  // DMA sources: A rows through the segment map per lane (32-bit byte offsets from p.A; rows beyond M - 1 re-read
+  // the last row, their results are never stored), W rows from a tile-uniform base + lane part
+  unsigned la[2][2], lw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
+    lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int m = min(m0 + hh * 128 + wave * 16 + j * 8 + srow, p.M - 1);
+      const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
+      la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
+    }
+  }
+  const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2;
-  const size_t a128 = (size_t)128 * p.lda * 2, a8 = (size_t)8 * p.lda * 2;
   const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
 
   auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
     const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
     const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
     if (op == 0)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA + hh * a128 + j * a8 + (size_t)i * (BK * 2) + la[j]),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA + (size_t)i * (BK * 2) + la[hh][j]),
                                        (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, 0, 0);
     else
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW + hh * w128 + j * w8 + (size_t)i * (BK * 2) + lw[j]),
@@ -209,9 +220,16 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const int ldcb = out2 ? p.ldc2 : p.ldc;
   const int epi = out2 ? p.epi2 : p.epi;
   const int ncol0 = out2 ? n0 - p.n_split : n0;
+  const bool has_res = epi == DK_EPI_GATE_RES || epi == DK_EPI_RES;
+  // a tile that lies inside one row segment of every map and inside M evaluates the maps once (scalar unit);
+  // otherwise each lane walks its rows through the maps (fast == false)
+  auto inside = [&](int len) { return m0 / len == (m0 + T256 - 1) / len; };
+  const bool fast = m0 + T256 <= p.M && inside(p.c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
+                    (epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
+  const int mrow0 = m0 + wm * 128;  // first GEMM row of this wave's block
   const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
-  const size_t physR0 = (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128;
-  const bf16_t* gate_row = p.gate ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
+  const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128 : 0;
+  const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
   const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
   const int rrow = lane >> 3, rchunk = lane & 7;   // read-back: 8 rows x 8 chunks of 16 B per instruction
 
@@ -234,43 +252,91 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       unpack2bf(bb.x, bias4[0], bias4[1]);
       unpack2bf(bb.y, bias4[2], bias4[3]);
     }
-    if (epi == DK_EPI_GATE_RES) {
-      const uint2 gg = *(const uint2*)(gate_row + col);
-      unpack2bf(gg.x, gate4[0], gate4[1]);
-      unpack2bf(gg.y, gate4[2], gate4[3]);
-    }
-#pragma unroll 4
-    for (int itr = 0; itr < 16; ++itr) {
-      const int row = itr * 8 + rrow;  // row inside the wave's 128-row block
-      const f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
-      float vv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
-      if (epi == DK_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = gelu_erf_f(vv[e]);
-      } else if (epi == DK_EPI_BIAS_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = silu_f(vv[e]);
-      } else if (epi == DK_EPI_GATE_RES || epi == DK_EPI_RES) {
-        const uint2 rr = *(const uint2*)(p.res + (physR0 + row) * (size_t)p.ldr + col);
-        float r4[4];
-        unpack2bf(rr.x, r4[0], r4[1]);
-        unpack2bf(rr.y, r4[2], r4[3]);
-        if (epi == DK_EPI_GATE_RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] = r4[e] + round_bf16(gate4[e] * vv[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] += r4[e];
-        }
+    // the row loop is instantiated twice -- tile-uniform maps (FAST) or a per-lane walk through the maps -- so that
+    // the common case keeps its short body (one v_add per address, batched loads)
+    auto rows = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      if (FAST && epi == DK_EPI_GATE_RES) {
+        const uint2 gg = *(const uint2*)(gate_row + col);
+        unpack2bf(gg.x, gate4[0], gate4[1]);
+        unpack2bf(gg.y, gate4[2], gate4[3]);
       }
-      uint2 o2;
-      o2.x = pack2bf(vv[0], vv[1]);
-      o2.y = pack2bf(vv[2], vv[3]);
-      *(uint2*)(Cb + (physC0 + row) * (size_t)ldcb + ocol) = o2;
-    }
+      // row walk of the slow path: (segment, row inside it) of this lane's current row in each map; 8 rows per step
+      int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
+      if (!FAST) {
+        const int ms = mrow0 + rrow;
+        c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
+        if (has_res) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
+        if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
+      }
+#pragma unroll 4
+      for (int itr = 0; itr < 16; ++itr) {
+        const int row = itr * 8 + rrow;  // row inside the wave's 128-row block
+        size_t crow = physC0 + row, rrow_phys = physR0 + row;
+        bool valid = true;
+        if (!FAST) {
+          valid = mrow0 + row < p.M;
+          crow = (size_t)c_seg * p.c_seg_stride + c_rem;
+          rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
+          if (epi == DK_EPI_GATE_RES && valid) {
+            const uint2 gg = *(const uint2*)(p.gate + (size_t)g_seg * p.gate_stride + col);
+            unpack2bf(gg.x, gate4[0], gate4[1]);
+            unpack2bf(gg.y, gate4[2], gate4[3]);
+          }
+          for (c_rem += 8; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
+          if (has_res)
+            for (r_rem += 8; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
+          if (epi == DK_EPI_GATE_RES)
+            for (g_rem += 8; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
+        }
+        const f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
+        if (epi == DK_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = gelu_erf_f(vv[e]);
+        } else if (epi == DK_EPI_BIAS_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = silu_f(vv[e]);
+        } else if (has_res) {
+          uint2 rr = make_uint2(0u, 0u);
+          if (FAST || valid) rr = *(const uint2*)(p.res + rrow_phys * (size_t)p.ldr + col);
+          float r4[4];
+          unpack2bf(rr.x, r4[0], r4[1]);
+          unpack2bf(rr.y, r4[2], r4[3]);
+          if (epi == DK_EPI_GATE_RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = r4[e] + round_bf16(gate4[e] * vv[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] += r4[e];
+          }
+        }
+        uint2 o2;
+        o2.x = pack2bf(vv[0], vv[1]);
+        o2.y = pack2bf(vv[2], vv[3]);
+        if (FAST || valid) *(uint2*)(Cb + crow * (size_t)ldcb + ocol) = o2;
+      }
+    };
+    if (fast)
+      rows(std::true_type{});
+    else
+      rows(std::false_type{});
   }
+}
+
+bool dk_gemm256v3_eligible(const GemmParams& p) {
+  if (p.conv || p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldc % 4 != 0) return false;
+  if (p.n_split % 256 != 0 || (p.n_split > 0 && (p.C2 == nullptr || p.ldc2 % 4 != 0 || p.n_split >= p.N))) return false;
+  if (p.a_seg_len <= 0 || p.c_seg_len <= 0) return false;
+  const bool res1 = p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES;
+  const bool res2 = p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES);
+  if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 4 != 0)) return false;
+  if ((p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES)) && (p.gate == nullptr || p.gate_seg_len <= 0)) return false;
+  // 32-bit byte offsets on the DMA side: the A rows this problem touches and 8 rows of W
+  const size_t a_rows = (size_t)((p.M - 1) / p.a_seg_len) * p.a_seg_stride + (size_t)((p.M - 1) % p.a_seg_len) + 1;
+  return a_rows * (size_t)p.lda * 2 < (1ull << 32) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
 }
 
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream) {
@@ -281,4 +347,24 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles
   }
   hipLaunchKernelGGL(dk_gemm256v3_kernel, dim3(tiles_a + tiles_b), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b);
   return 0;
+}
+
+// tile-parallel launch of `p` and, optionally, a second problem `p2` with the same N, K, alpha and epilogue
+int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream) {
+  DK_REQUIRE(dk_gemm256v3_eligible(p), "gemm256v3: shape / strides not eligible");
+  if (p2) {
+    DK_REQUIRE(dk_gemm256v3_eligible(*p2), "gemm256v3: second problem not eligible");
+    DK_REQUIRE(p2->N == p.N && p2->K == p.K && p2->epi == p.epi && p2->alpha == p.alpha && p2->n_split == p.n_split &&
+                   (p.n_split == 0 || p2->epi2 == p.epi2),
+               "grouped GEMM: N, K, epilogue must match");
+  }
+  const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
+  const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;
+  double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
+  dk_prof_begin(0, work, stream);
+  const int rc = dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, tiles_a, tiles_b, stream);
+  dk_prof_end(stream);
+  DK_CHECK_HIP(hipGetLastError());
+  return rc;
 }

@@ -158,6 +158,44 @@ def test_gemm_streamk_joint_stream_in_place(dev):
         assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP, mode
 
 
+@pytest.mark.parametrize("epi", ["bias", "gate_res", "res"])
+@pytest.mark.parametrize("B,S_t,S_i", [(2, 589, 64), (3, 77, 11), (1, 300, 0)])
+def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi):
+    """The 16x16x32-MFMA 256^2 kernel on the text stream of a joint [B, S_t + S_i] buffer: M = B * S_t is not
+    a multiple of 256 and (B > 1) tiles straddle the row segments of every map (A, C, residual, gate), so
+    the per-lane row walk of the tail and the clamped DMA rows are exercised; rows of the other stream and
+    the rows behind M must stay untouched."""
+    from diffusionkit_amd import ops
+    h, N = 192, 512
+    S = S_t + S_i
+    att, X = randn(B, S, h, seed=40), randn(B, S, N, seed=41)
+    w, b, gate = randn(N, h, seed=42, scale=0.08), randn(N, seed=43, scale=0.1), randn(B, 2 * N, seed=44)
+    Xd, attd, gd = g(X, dev), g(att, dev), g(gate, dev)
+    kw = dict(A=attd, W=g(w, dev), C=Xd, bias=g(b, dev), M=B * S_t, N=N, K=h, lda=h, ldc=N,
+              a_seg_len=S_t, a_seg_stride=S, c_seg_len=S_t, c_seg_stride=S, alpha=1.0)
+    o = bf16r(att[:, :S_t] @ w.t() + b)
+    ref = X.clone()
+    if epi == "bias":
+        kw.update(epilogue=ops.DK_EPI_BIAS)
+        ref[:, :S_t] = o
+    elif epi == "res":
+        kw.update(epilogue=ops.DK_EPI_RES, res=Xd, ldr=N, r_seg_len=S_t, r_seg_stride=S)
+        ref[:, :S_t] = X[:, :S_t] + o
+    else:
+        kw.update(epilogue=ops.DK_EPI_GATE_RES, res=Xd, ldr=N, r_seg_len=S_t, r_seg_stride=S,
+                  gate=gd.data_ptr() + N * 2, gate_seg_len=S_t, gate_stride=2 * N)
+        ref[:, :S_t] = X[:, :S_t] + bf16r(gate[:, None, N:] * o)
+    try:
+        ops.tune("gemm", 9)
+        ops.gemm_desc_call(**kw)
+    finally:
+        ops.tune("gemm", -1)
+    got = Xd.float().cpu()
+    assert torch.equal(got[:, S_t:], X[:, S_t:])  # rows of the other stream untouched
+    assert rel_l2(ref[:, :S_t], got[:, :S_t]) < TOL_SINGLE_OP
+    assert max_abs(ref[:, :S_t], got[:, :S_t]) < 0.02 * float(ref.abs().max()) + 1e-2
+
+
 # ---- conv ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C,O,ups,res", [(1, 16, 16, 64, 128, False, False), (2, 8, 24, 128, 64, False, True),
                                                (1, 16, 8, 64, 64, True, False), (1, 32, 32, 128, 3, False, False)])
