@@ -26,6 +26,18 @@
 
 #include "dk_kernels.h"
 
+#ifndef DK_V3_ABL
+#define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n): 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile barrier
+#endif
+
+// placement of the 4 DMA pieces inside a 16-MFMA step: in front of MFMA slots PH, PH + STR, ... (PH0 / PH1 for the
+// two wave groups of a SIMD)
+#ifndef DK_V3_PH0
+#define DK_V3_PH0 0
+#define DK_V3_PH1 2
+#define DK_V3_STR 4
+#endif
+
 #define T256 256
 #define BK 64
 #define HALF_BYTES (128 * BK * 2)
@@ -93,15 +105,19 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2;
   const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
 
+  // LDS-DMA in the buffer form: SGPR resource (base, 4 GiB range) + 32-bit lane offset + scalar offset -- no 64-bit
+  // per-lane address and no VALU per piece
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
   auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
     const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
     const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
     if (op == 0)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA + (size_t)i * (BK * 2) + la[hh][j]),
-                                       (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, (int)la[hh][j],
+                                               i * (BK * 2), 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW + hh * w128 + j * w8 + (size_t)i * (BK * 2) + lw[j]),
-                                       (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, (int)lw[j],
+                                               (int)(hh * w128 + j * w8) + i * (BK * 2), 0, 0);
   };
   auto issue_tile = [&](int i) {
 #pragma unroll
@@ -117,7 +133,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
   // ---------------- K loop: register-pipelined, hand-counted LDS waits ----------------
-#define DK_LDS_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define DK_LDS_RD(DST, ADDR, OFF)                                                              \
+  do {                                                                                        \
+    if (!(DK_V3_ABL & 2) || !in_loop) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR)); \
+  } while (0)
 #define DK_RDW(SET, BUFOFF, KK)                    \
   do {                                             \
     const unsigned aW_ = offk[KK] + sW + (BUFOFF); \
@@ -150,8 +169,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #define DK_MMG(WSET, ASET, MB, TILE, G0, NG, PH, ON)                                                              \
   do {                                                                                                            \
     _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                           \
-      if ((NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) & 3) == 0 && ((e_ - (PH)) >> 2) < (NG))                  \
-        issue_piece((TILE), (G0) + ((e_ - (PH)) >> 2));                                                           \
+      if (!(DK_V3_ABL & 1) && (NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) % DK_V3_STR) == 0 && ((e_ - (PH)) / DK_V3_STR) < (NG)) \
+        issue_piece((TILE), (G0) + ((e_ - (PH)) / DK_V3_STR));                                                    \
       acc[e_ >> 2][(MB) + (e_ & 3)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##WSET[e_ >> 2], xf##ASET[e_ & 3], \
                                                                               acc[e_ >> 2][(MB) + (e_ & 3)], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   } while (0)
 #define DK_LOOP(PH)                                                                                            \
   for (int i = 0; i < nk; ++i) {                                                                               \
+    constexpr bool in_loop = true;                                                                             \
     const unsigned bo = (i & 1) * KT_BYTES;                                                                    \
     const bool on1 = i >= 1 && i + 1 < nk; /* second half of tile i+1 (first half went out in S3 of i-1) */     \
     DK_RDA_HI(1, bo, 0);                                                                                       \
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_WAIT8(4, wf1, xf0);                                                                                     \
     DK_MMG(1, 0, 0, 0, 0, 0, 0, false);                                                                        \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
-    __builtin_amdgcn_s_barrier();                                                                              \
+    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("" ::: "memory");                                                                             \
     DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */      \
     DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */      \
@@ -192,15 +212,16 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     asm volatile("" ::: "memory");
     // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not be
     //  live across a compiler-visible branch, see gemm256sk.hip)
+    constexpr bool in_loop = false;
     if (wm == 0) {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
-      DK_LOOP(0)
+      DK_LOOP(DK_V3_PH0)
       DK_WAIT8(0, wf0, xf0);
     } else {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
-      DK_LOOP(2)
+      DK_LOOP(DK_V3_PH1)
       DK_WAIT8(0, wf0, xf0);
     }
   }
