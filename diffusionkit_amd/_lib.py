@@ -103,6 +103,9 @@ SIGNATURES = {
     "dk_vae_bind": (_i32, [_vp, C.c_char_p, _vp]),
     "dk_vae_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "dk_vae_decode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dk_vae_encoder_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "dk_vae_encode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "dk_latent_sample_f32": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp]),
     "dk_profile_enable": (_i32, [_i32]),
     "dk_profile_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dk_tune_set": (_i32, [C.c_char_p, _i32]),

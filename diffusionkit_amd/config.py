@@ -147,6 +147,21 @@ class VAEDecoderConfig:
     group_norm_eps: float = 1e-5  # MLX nn.GroupNorm default (vae.py:34,72,78,381)
 
 
+@dataclass(frozen=True)
+class VAEEncoderConfig:
+    """reference config.py:135-140 (the image -> latent half used by img2img, vae.py:404-467)"""
+    in_channels: int = 3
+    out_channels: int = 32  # mean | logvar of the 16 latent channels
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    resnet_groups: int = 32
+    group_norm_eps: float = 1e-5
+
+
+def tiny_vae_encoder() -> VAEEncoderConfig:
+    return VAEEncoderConfig(block_out_channels=(64, 64, 128, 128), layers_per_block=1)
+
+
 def tiny_vae() -> VAEDecoderConfig:
     return VAEDecoderConfig(block_out_channels=(64, 64, 128, 128), layers_per_block=1)
 

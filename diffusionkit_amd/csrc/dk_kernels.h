@@ -27,7 +27,8 @@ struct GemmParams {
   int epi;
   // implicit-GEMM 3x3 conv (pad 1, stride 1) over NHWC input; M = cB*cH*cW output pixels,
   // K = 9*cC. If ups != 0 the conv input is the nearest-neighbour x2 upsampling of the stored
-  // [cB, cH/2, cW/2, cC] tensor (vae.py:20-25 folded into the gather).
+  // [cB, cH/2, cW/2, cC] tensor (vae.py:20-25 folded into the gather); ups == 2: stride-2 conv over the stored
+  // [cB, 2*cH, 2*cW, cC] tensor padded by one zero row / column at the bottom / right (vae.py:141-143).
   int conv;
   int cB, cH, cW, cC, ups;
   const bf16_t* zeros;  // >= 128 B of zeros (padding taps)
@@ -109,3 +110,5 @@ int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t st
 int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream);
 int dk_launch_pad_channels(const float* x, bf16_t* y, long npix, int C, int Cpad, hipStream_t stream);
 int dk_launch_image_post(const bf16_t* x, int ldx, float* img, unsigned char* u8, long npix, hipStream_t stream);
+int dk_launch_latent_sample(const bf16_t* mom, int ldm, const float* noise, float* out, long npix, int L, hipStream_t stream);
+int dk_launch_bf16_rows_to_f32(const bf16_t* x, int ldx, float* y, long npix, int C, hipStream_t stream);

@@ -69,7 +69,8 @@ extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) {
   p.alpha = 1.0f; p.epi = d->epilogue;
   p.conv = 1; p.cB = d->B; p.cH = d->H; p.cW = d->W; p.cC = d->C; p.ups = d->upsample;
   p.zeros = (const bf16_t*)d->zeros;
-  if (d->upsample) DK_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "upsampled conv needs even output size");
+  DK_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "upsample: 0 plain, 1 nearest-x2 input view, 2 stride-2 (downsample)");
+  if (d->upsample == 1) DK_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "upsampled conv needs even output size");
   return dk_launch_gemm(p, S_(stream));
 }
 
@@ -618,7 +619,8 @@ extern "C" int dk_vae_create(const dk_vae_config* cfg, dk_vae** out) {
   DK_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 4, "1..4 resolution levels");
   for (int i = 0; i < cfg->n_blocks; ++i)
     DK_REQUIRE(cfg->block_out_channels[i] % 64 == 0, "VAE channel counts must be multiples of 64");
-  DK_REQUIRE(cfg->in_channels <= 64 && cfg->out_channels <= 4, "latent channels <= 64, image channels <= 4");
+  DK_REQUIRE(cfg->in_channels >= 1 && cfg->in_channels <= 64 && cfg->out_channels >= 1 && cfg->out_channels <= 64,
+             "input / output channels of the VAE halves: 1..64");
   dk_vae* v = new dk_vae();
   v->cfg = *cfg;
   *out = v;
@@ -789,4 +791,97 @@ extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int3
   DK_TRY(R.conv(v->T1, raw, H, W, C, cf.out_channels, "conv_out", 0, nullptr, 4));
   DK_TRY(dk_launch_image_post(raw, 4, image_f32, image_u8, (long)batch * H * W, st));
   return R.rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAE encoder engine (vae.py:404-467; img2img entry mlx/__init__.py:586-594).  Same handle type as the
+// decoder: a dk_vae created with the encoder's config (in 3, out 32, layers_per_block 2) and bound to
+// the encoder's module names (conv_in, down_blocks.{i}.resnets.{r}, down_blocks.{i}.downsample,
+// mid_blocks.{0,1,2}, conv_norm_out, conv_out).
+// ---------------------------------------------------------------------------------------------
+static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
+  const dk_vae_config& cf = v->cfg;
+  size_t maxel = (size_t)B * H * W * 64;  // channel-padded input image
+  {
+    size_t h = H, w = W;
+    int Cprev = cf.block_out_channels[0];
+    for (int i = 0; i < cf.n_blocks; ++i) {
+      const int Cout = cf.block_out_channels[i];
+      const size_t e = (size_t)B * h * w * (size_t)(Cprev > Cout ? Cprev : Cout);
+      if (e > maxel) maxel = e;
+      if (i < cf.n_blocks - 1) { h /= 2; w /= 2; }
+      Cprev = Cout;
+    }
+  }
+  const size_t act = maxel * 2;
+  v->bufA = (bf16_t*)c.take(act);
+  v->bufB = (bf16_t*)c.take(act);
+  v->T1 = (bf16_t*)c.take(act);
+  v->Y = (bf16_t*)c.take(act);
+  v->SC = (bf16_t*)c.take(act);
+  v->LAT = (bf16_t*)c.take((size_t)B * H * W * 64 * 2);
+  v->ZERO = (bf16_t*)c.take(256);
+  const int Cm = cf.block_out_channels[cf.n_blocks - 1];
+  const size_t tok = ((size_t)H >> (cf.n_blocks - 1)) * ((size_t)W >> (cf.n_blocks - 1));
+  v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
+  v->Vt = (bf16_t*)c.take(tok * Cm * 2);
+  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 8) * 2);
+  v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  return c.off;
+}
+extern "C" size_t dk_vae_encoder_workspace_bytes(const dk_vae* v, int32_t batch, int32_t image_h, int32_t image_w) {
+  dk_vae tmp = *v;
+  Carver c(nullptr, 0);
+  return vae_carve_encoder(&tmp, c, batch, image_h, image_w) + 256;
+}
+
+extern "C" int dk_vae_encode(dk_vae* v, const float* image, int32_t batch, int32_t image_h, int32_t image_w, void* moments_bf16,
+                             int32_t ldm, float* moments_f32, void* workspace, size_t workspace_bytes, void* stream) {
+  DK_REQUIRE(v && image && workspace && (moments_bf16 || moments_f32), "null argument");
+  DK_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const dk_vae_config& cf = v->cfg;
+  const int down = 1 << (cf.n_blocks - 1);
+  DK_REQUIRE(image_h % down == 0 && image_w % down == 0, "image size must be a multiple of the VAE down-scaling factor");
+  const int ldo = (cf.out_channels + 3) / 4 * 4;
+  DK_REQUIRE(moments_bf16 == nullptr || ldm >= ldo, "moments leading dimension too small (multiple of 4 >= out_channels)");
+  Carver c(workspace, workspace_bytes);
+  const size_t need_bytes = vae_carve_encoder(v, c, batch, image_h, image_w);
+  DK_REQUIRE(need_bytes <= workspace_bytes, "workspace too small");
+  VaeRun R{v, S_(stream), batch};
+  hipStream_t st = R.st;
+  DK_CHECK_HIP(hipMemsetAsync(v->ZERO, 0, 256, st));
+  int H = image_h, W = image_w;
+  DK_TRY(dk_launch_pad_channels(image, v->LAT, (long)batch * H * W, cf.in_channels, 64, st));
+  bf16_t *cur = v->bufA, *nxt = v->bufB;
+  int C = cf.block_out_channels[0];
+  DK_TRY(R.conv(v->LAT, cur, H, W, 64, C, "conv_in", 0, nullptr, C));
+  for (int i = 0; i < cf.n_blocks; ++i) {
+    const int Cout = cf.block_out_channels[i];
+    for (int r = 0; r < cf.layers_per_block; ++r) {
+      const std::string p = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(r);
+      DK_TRY(R.resnet(cur, nxt, H, W, r == 0 ? C : Cout, Cout, p)); std::swap(cur, nxt);
+    }
+    C = Cout;
+    if (i < cf.n_blocks - 1) {  // pad (0,1),(0,1) + conv k3 s2 p0 (vae.py:141-143)
+      H /= 2; W /= 2;
+      DK_TRY(R.conv(cur, nxt, H, W, C, C, "down_blocks." + std::to_string(i) + ".downsample", 2, nullptr, C)); std::swap(cur, nxt);
+    }
+  }
+  DK_TRY(R.resnet(cur, nxt, H, W, C, C, "mid_blocks.0")); std::swap(cur, nxt);
+  DK_TRY(R.attention(cur, nxt, H, W, C, "mid_blocks.1")); std::swap(cur, nxt);
+  DK_TRY(R.resnet(cur, nxt, H, W, C, C, "mid_blocks.2")); std::swap(cur, nxt);
+  DK_TRY(R.gn(cur, v->T1, (long)H * W, C, "conv_norm_out", 1));
+  bf16_t* mom = moments_bf16 ? (bf16_t*)moments_bf16 : v->Y;
+  const int ld = moments_bf16 ? ldm : ldo;
+  DK_TRY(R.conv(v->T1, mom, H, W, C, cf.out_channels, "conv_out", 0, nullptr, ld));
+  if (moments_f32) DK_TRY(dk_launch_bf16_rows_to_f32(mom, ld, moments_f32, (long)batch * H * W, cf.out_channels, st));
+  return R.rc;
+}
+
+extern "C" int dk_latent_sample_f32(const void* moments_bf16, int32_t ldm, const float* noise, float* latent, int64_t n_pixels,
+                                    int32_t latent_channels, void* stream) {
+  DK_REQUIRE(moments_bf16 && noise && latent && n_pixels > 0 && latent_channels > 0 && ldm >= 2 * latent_channels, "bad argument");
+  return dk_launch_latent_sample((const bf16_t*)moments_bf16, ldm, noise, latent, (long)n_pixels, latent_channels, S_(stream));
 }

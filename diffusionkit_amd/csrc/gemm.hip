@@ -13,8 +13,9 @@
 // The MFMA is issued with operands swapped (W-fragment as A, X-fragment as B) so each lane
 // ends up owning one output row and 4-element runs of consecutive columns: the epilogue
 // (bias, GELU, gate*x+residual) then works on 8-byte vectors.
-// AMODE=1 turns the A loader into an im2col gather for 3x3/pad-1 convolution over NHWC
-// (optionally reading a nearest-x2-upsampled view), padding taps read a zero page.
+// AMODE=1 turns the A loader into an im2col gather for 3x3 convolution over NHWC: pad 1 / stride 1
+// (optionally reading a nearest-x2-upsampled view), or stride 2 over the input padded by one row and
+// column at the bottom / right (the VAE encoder's downsample, vae.py:141-143); padding taps read a zero page.
 #include "dk_kernels.h"
 
 #define BM 128
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
       const int b = m / hw, rem = m - b * hw;
       cy[i] = rem / p.cW;
       cx[i] = rem - cy[i] * p.cW;
-      const int Hs = p.ups ? (p.cH >> 1) : p.cH, Ws = p.ups ? (p.cW >> 1) : p.cW;
+      // stored input size: ups 1 = nearest-x2 view of a half-size tensor, ups 2 = stride-2 conv over a double-size one
+      const int Hs = p.ups == 1 ? (p.cH >> 1) : p.ups == 2 ? (p.cH << 1) : p.cH;
+      const int Ws = p.ups == 1 ? (p.cW >> 1) : p.ups == 2 ? (p.cW << 1) : p.cW;
       cimg[i] = (long)b * Hs * Ws * p.cC + chunk * 8;
       a_src[i] = p.zeros + chunk * 8;
     }
@@ -92,12 +95,16 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
     if (AMODE == 1) {
       const int tap = kt / cpt, cb = (kt - tap * cpt) * BK;
       const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-      const int Ws = p.ups ? (p.cW >> 1) : p.cW;
+      const int Ws = p.ups == 1 ? (p.cW >> 1) : p.ups == 2 ? (p.cW << 1) : p.cW;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int iy = cy[i] + ky, ix = cx[i] + kx;
-        const bool ok = (iy >= 0) && (iy < p.cH) && (ix >= 0) && (ix < p.cW);
-        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+        int iy = cy[i] + ky, ix = cx[i] + kx;
+        bool ok = (iy >= 0) && (iy < p.cH) && (ix >= 0) && (ix < p.cW);
+        int sy = p.ups == 1 ? (iy >> 1) : iy, sx = p.ups == 1 ? (ix >> 1) : ix;
+        if (p.ups == 2) {  // stride 2 over the input padded by one row / column at the bottom / right (vae.py:141-143)
+          sy = 2 * cy[i] + ky + 1, sx = 2 * cx[i] + kx + 1;
+          ok = sy < 2 * p.cH && sx < 2 * p.cW;
+        }
         const bf16_t* src = ok ? (p.A + cimg[i] + ((long)sy * Ws + sx) * p.cC + cb) : a_src[i];
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(abase + i * 1024), 16, 0, 0);
       }

@@ -37,6 +37,13 @@
 #define DK_V3_PH1 2
 #define DK_V3_STR 4
 #endif
+// pieces per step, in issue order: the step behind the tile barrier (S3), then S0, S1, S2 of the next K-tile
+#ifndef DK_V3_N3
+#define DK_V3_N3 4
+#define DK_V3_N0 4
+#define DK_V3_N1 0
+#define DK_V3_N2 0
+#endif
 
 #define T256 256
 #define BK 64
@@ -183,20 +190,20 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     const bool on1 = i >= 1 && i + 1 < nk; /* second half of tile i+1 (first half went out in S3 of i-1) */     \
     DK_RDA_HI(1, bo, 0);                                                                                       \
     DK_WAIT8(4, wf0, xf0);                                                                                     \
-    DK_MMG(0, 0, 0, i + 1, 4, 4, PH, on1);                                                                     \
+    DK_MMG(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1);                                                                   \
     DK_RDW(1, bo, 1);                                                                                          \
     DK_RDA_LO(0, bo, 1);                                                                                       \
     DK_WAIT4(8, xf1);                                                                                          \
-    DK_MMG(0, 1, 4, 0, 0, 0, 0, false);                                                                        \
+    DK_MMG(0, 1, 4, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, on1);                                                                     \
     DK_RDA_HI(1, bo, 1);                                                                                       \
     DK_WAIT8(4, wf1, xf0);                                                                                     \
-    DK_MMG(1, 0, 0, 0, 0, 0, 0, false);                                                                        \
+    DK_MMG(1, 0, 0, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, on1);                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("" ::: "memory");                                                                             \
     DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */      \
     DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */      \
-    DK_MMG(1, 1, 4, i + 2, 0, 4, PH, i + 2 < nk);                                                              \
+    DK_MMG(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk);                                                              \
   }
 
   {

@@ -245,3 +245,34 @@ int dk_launch_image_post(const bf16_t* x, int ldx, float* img, unsigned char* u8
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// encode_image_to_latents tail (mlx/__init__.py:586-594): moments [npix, ldm >= 2L] (mean | logvar) ->
+// latent = mean + exp(0.5 * clip(logvar, -30, 20)) * noise, fp32 like the reference (its encoder output is fp32)
+__global__ void dk_latent_sample_kernel(const bf16_t* mom, int ldm, const float* noise, float* out, long npix, int L) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * L) return;
+  const int c = (int)(i % L);
+  const long pix = i / L;
+  const float mean = bf2f(mom[pix * ldm + c]);
+  const float logvar = fminf(fmaxf(bf2f(mom[pix * ldm + L + c]), -30.0f), 20.0f);
+  out[i] = mean + expf(0.5f * logvar) * noise[i];
+}
+int dk_launch_latent_sample(const bf16_t* mom, int ldm, const float* noise, float* out, long npix, int L, hipStream_t stream) {
+  const long n = npix * L;
+  hipLaunchKernelGGL(dk_latent_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mom, ldm, noise, out, npix, L);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// bf16 [npix, ldx] -> fp32 [npix, C]
+__global__ void dk_bf16_rows_to_f32_kernel(const bf16_t* x, int ldx, float* y, long npix, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * C) return;
+  y[i] = bf2f(x[(i / C) * ldx + (i % C)]);
+}
+int dk_launch_bf16_rows_to_f32(const bf16_t* x, int ldx, float* y, long npix, int C, hipStream_t stream) {
+  const long n = npix * C;
+  hipLaunchKernelGGL(dk_bf16_rows_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, y, npix, C);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -219,3 +219,65 @@ class VAEDecoderEngine:
         """VAEDecoder.__call__ (vae.py:386-401): returns the un-clipped decoder output [B,8h,8w,3]."""
         _, _, raw = self.decode(x, want_raw=True)
         return raw[..., :3]
+
+
+class VAEEncoderEngine:
+    """Drop-in for the reference ``VAEEncoder`` (vae.py:404-467): image in [-1, 1] -> moments."""
+
+    def __init__(self, config, packed_weights: Dict[str, Tensor]):
+        self.lib = _lib.load()
+        self.config = config
+        c = _lib.dk_vae_config()
+        c.in_channels, c.out_channels = config.in_channels, config.out_channels
+        for i, ch in enumerate(config.block_out_channels):
+            c.block_out_channels[i] = ch
+        c.n_blocks = len(config.block_out_channels)
+        c.layers_per_block, c.resnet_groups = config.layers_per_block, config.resnet_groups
+        c.group_norm_eps = config.group_norm_eps
+        h = C.c_void_p()
+        _lib.check(self.lib.dk_vae_create(C.byref(c), C.byref(h)), "dk_vae_create")
+        self._h = h
+        self.weights = packed_weights
+        for name, t in packed_weights.items():
+            _require_cuda(t, name, torch.bfloat16)
+            _lib.check(self.lib.dk_vae_bind(self._h, name.encode(), t.data_ptr()), f"bind {name}")
+        self._ws = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.dk_vae_destroy(self._h)
+            self._h = None
+
+    def encode(self, image: Tensor):
+        """image: f32 [B,H,W,3] in [-1,1] -> moments bf16 [B,H/8,W/8,ldm] (mean | logvar in the first
+        ``out_channels`` columns)."""
+        image = image.to(torch.float32).contiguous()
+        _require_cuda(image, "image")
+        b, H, W, _ = image.shape
+        nbytes = self.lib.dk_vae_encoder_workspace_bytes(self._h, b, H, W)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        ldm = (self.config.out_channels + 3) // 4 * 4
+        mom = torch.empty(b, H // down, W // down, ldm, dtype=torch.bfloat16, device=image.device)
+        _lib.check(self.lib.dk_vae_encode(self._h, image.data_ptr(), b, H, W, mom.data_ptr(), ldm, None,
+                                          self._ws.data_ptr(), self._ws.numel(), _stream()), "dk_vae_encode")
+        return mom
+
+    def __call__(self, image: Tensor) -> Tensor:
+        """VAEEncoder.__call__ (vae.py:456-467): hidden [B,H/8,W/8,out_channels]."""
+        return self.encode(image)[..., :self.config.out_channels]
+
+    def sample(self, moments: Tensor, noise: Tensor) -> Tensor:
+        """encode_image_to_latents tail (__init__.py:588-594): mean + exp(0.5 * clip(logvar)) * noise, f32."""
+        _require_cuda(moments, "moments", torch.bfloat16)
+        noise = noise.to(torch.float32).contiguous()
+        _require_cuda(noise, "noise")
+        L = self.config.out_channels // 2
+        b, h, w, ldm = moments.shape
+        assert noise.shape == (b, h, w, L), (noise.shape, (b, h, w, L))
+        out = torch.empty(b, h, w, L, dtype=torch.float32, device=moments.device)
+        _lib.check(self.lib.dk_latent_sample_f32(moments.data_ptr(), ldm, noise.data_ptr(), out.data_ptr(), b * h * w, L,
+                                                 _stream()), "dk_latent_sample_f32")
+        return out

@@ -252,6 +252,55 @@ def vae_decoder_checkpoint_to_reference(sd: StateDict, cfg: VAEDecoderConfig, pr
     return {k: out[k] for k in want}
 
 
+def vae_encoder_checkpoint_to_reference(sd: StateDict, cfg, prefix: str = "encoder.") -> StateDict:
+    """Stability / BFL autoencoder ``encoder.*`` tensors -> reference VAEEncoder names and layouts
+    (behaviour of model_io.py:489-563; written as an explicit table, not chained substring replaces)."""
+    out: StateDict = {}
+
+    def conv(t):  # OIHW -> OHWI
+        return t.permute(0, 2, 3, 1).contiguous()
+
+    for k0, t in sd.items():
+        if not k0.startswith(prefix):
+            continue
+        k = k0[len(prefix):]
+        m = re.fullmatch(r"(.+)\.(weight|bias)", k)
+        if not m:
+            continue
+        stem, leaf = m.group(1), m.group(2)
+        w = leaf == "weight"
+        if stem in ("conv_in", "conv_out"):
+            out[f"{stem}.{leaf}"] = conv(t) if w else t
+        elif stem == "norm_out":
+            out[f"conv_norm_out.{leaf}"] = t
+        elif (m2 := re.fullmatch(r"mid\.block_([12])\.(norm1|conv1|norm2|conv2)", stem)):
+            idx = 0 if m2.group(1) == "1" else 2
+            out[f"mid_blocks.{idx}.{m2.group(2)}.{leaf}"] = conv(t) if (w and "conv" in m2.group(2)) else t
+        elif (m2 := re.fullmatch(r"mid\.attn_1\.(norm|q|k|v|proj_out)", stem)):
+            name = {"norm": "group_norm", "q": "query_proj", "k": "key_proj", "v": "value_proj", "proj_out": "out_proj"}[m2.group(1)]
+            out[f"mid_blocks.1.{name}.{leaf}"] = t[:, :, 0, 0].contiguous() if (w and name != "group_norm") else t
+        elif (m2 := re.fullmatch(r"down\.(\d+)\.block\.(\d+)\.(norm1|conv1|norm2|conv2|nin_shortcut)", stem)):
+            base = f"down_blocks.{m2.group(1)}.resnets.{m2.group(2)}"
+            part = m2.group(3)
+            if part == "nin_shortcut":
+                out[f"{base}.conv_shortcut.{leaf}"] = t[:, :, 0, 0].contiguous() if w else t
+            else:
+                out[f"{base}.{part}.{leaf}"] = conv(t) if (w and "conv" in part) else t
+        elif (m2 := re.fullmatch(r"down\.(\d+)\.downsample\.conv", stem)):
+            out[f"down_blocks.{m2.group(1)}.downsample.{leaf}"] = conv(t) if w else t
+        else:
+            raise CheckpointError(f"unknown VAE encoder key: {k0}")
+    from .weights import vae_encoder_weight_shapes
+    want = vae_encoder_weight_shapes(cfg)
+    missing = sorted(set(want) - set(out))
+    if missing:
+        raise CheckpointError(f"VAE checkpoint lacks {len(missing)} encoder tensors, first: {missing[:3]}")
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise CheckpointError(f"{k}: shape {tuple(out[k].shape)} != expected {shp}")
+    return {k: out[k] for k in want}
+
+
 # ---------------------------------------------------------------------------------------------
 # entry points used by the pipelines (local_ckpt={"mmdit": path_or_dict, "vae_decoder": path_or_dict})
 # ---------------------------------------------------------------------------------------------
@@ -274,3 +323,11 @@ def load_vae_decoder_checkpoint(src, cfg: VAEDecoderConfig) -> StateDict:
         return sd
     pre = "first_stage_model.decoder." if any(k.startswith("first_stage_model.decoder.") for k in sd) else "decoder."
     return vae_decoder_checkpoint_to_reference(sd, cfg, prefix=pre)
+
+
+def load_vae_encoder_checkpoint(src, cfg) -> StateDict:
+    sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if any(k.startswith("down_blocks.") for k in sd):
+        return sd
+    pre = "first_stage_model.encoder." if any(k.startswith("first_stage_model.encoder.") for k in sd) else "encoder."
+    return vae_encoder_checkpoint_to_reference(sd, cfg, prefix=pre)

@@ -81,13 +81,19 @@ def zero_page(device) -> Tensor:
     return _zero_pages[key]
 
 
-def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False, res: Optional[Tensor] = None) -> Tensor:
-    """nn.Conv2d k3 s1 p1 on NHWC; w: [O,3,3,C] (or flattened [O, 9C]); C multiple of 64."""
+def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False, res: Optional[Tensor] = None,
+            downsample: bool = False) -> Tensor:
+    """nn.Conv2d k3 on NHWC; w: [O,3,3,C] (or flattened [O, 9C]); C multiple of 64.  Default: stride 1, pad 1
+    (``upsample``: over the nearest-x2 view of x); ``downsample``: stride 2 over x padded by one zero row /
+    column at the bottom / right (vae.py:141-143)."""
+    assert not (upsample and downsample)
     lib = _lib.load()
     _require_cuda(x, "x", BF)
     _require_cuda(w, "w", BF)
     B, Hs, Ws, Cc = x.shape
-    H, W_ = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    H, W_ = (Hs * 2, Ws * 2) if upsample else (Hs // 2, Ws // 2) if downsample else (Hs, Ws)
+    if downsample:
+        assert Hs % 2 == 0 and Ws % 2 == 0, "stride-2 conv needs even input sizes"
     O = w.shape[0]
     ldy = (O + 3) // 4 * 4
     y = torch.empty(B, H, W_, ldy, dtype=BF, device=x.device)
@@ -96,7 +102,7 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False
     d.zeros = zero_page(x.device).data_ptr()
     d.B, d.H, d.W, d.C, d.O = B, H, W_, Cc, O
     d.ldy, d.ldr = ldy, (res.shape[-1] if res is not None else 0)
-    d.upsample = int(upsample)
+    d.upsample = 2 if downsample else int(upsample)
     d.epilogue = DK_EPI_RES if res is not None else DK_EPI_BIAS
     _lib.check(lib.dk_conv3x3_bf16(C.byref(d), _stream()), "dk_conv3x3_bf16")
     return y[..., :O]

@@ -23,10 +23,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import (MMDIT_CKPT, MODEL_CONFIG, T5_MAX_LENGTH, MMDiTConfig, VAEDecoderConfig)
-from .engine import MMDiTEngine, VAEDecoderEngine, _stream
+from .config import (MMDIT_CKPT, MODEL_CONFIG, T5_MAX_LENGTH, MMDiTConfig, VAEDecoderConfig, VAEEncoderConfig)
+from .engine import MMDiTEngine, VAEDecoderEngine, VAEEncoderEngine, _stream
 from .sampler import FluxSampler, ModelSamplingDiscreteFlow, get_sigmas, max_denoise
-from .weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
+from .weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_encoder_weights, synth_vae_weights
 
 logger = logging.getLogger(__name__)
 Tensor = torch.Tensor
@@ -93,6 +93,7 @@ class DiffusionPipeline:
         device: Union[str, torch.device, None] = None,
         mmdit_config: Optional[MMDiTConfig] = None,
         vae_config: Optional[VAEDecoderConfig] = None,
+        vae_encoder_config: Optional[VAEEncoderConfig] = None,
         weights_seed: int = 1234,
         text_len: Optional[int] = None,
         packed_weights: Optional[dict] = None,
@@ -111,6 +112,7 @@ class DiffusionPipeline:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.mmdit_config = mmdit_config or MODEL_CONFIG[model_version]
         self.vae_config = vae_config or VAEDecoderConfig()
+        self.vae_encoder_config = vae_encoder_config or VAEEncoderConfig()
         self.weights_seed = weights_seed
         self._text_len_override = text_len
         self._packed_weights = packed_weights  # {"mmdit": ..., "vae_decoder": ...} already in engine layout
@@ -158,6 +160,22 @@ class DiffusionPipeline:
                 named = synth_vae_weights(self.vae_config, seed=self.weights_seed + 1, device="cpu")
             self.decoder = VAEDecoderEngine(self.vae_config, pack_vae(self.vae_config, named, self.device))
 
+    def load_vae_encoder(self):
+        """The image -> latent half is only needed by img2img (``image_path=``); built on first use
+        (mlx/__init__.py:586-588 loads it next to the decoder)."""
+        if hasattr(self, "encoder"):
+            return
+        cfg = self.vae_encoder_config
+        if self._packed_weights is not None and "vae_encoder" in self._packed_weights:
+            self.encoder = VAEEncoderEngine(cfg, self._packed_weights["vae_encoder"])
+            return
+        if isinstance(self.local_ckpt, dict) and "vae_encoder" in self.local_ckpt:
+            from .model_io import load_vae_encoder_checkpoint
+            named = load_vae_encoder_checkpoint(self.local_ckpt["vae_encoder"], cfg)
+        else:
+            named = synth_vae_encoder_weights(cfg, seed=self.weights_seed + 2, device="cpu")
+        self.encoder = VAEEncoderEngine(cfg, pack_vae(cfg, named, self.device))
+
     # -- text conditioning (outside the hot path) ------------------------------------------------
     def set_text_encoder(self, fn: Callable) -> None:
         """Plug in a callable ``fn(text, cfg_weight, negative_text) -> (conditioning, pooled)``
@@ -202,14 +220,18 @@ class DiffusionPipeline:
     ):
         """mlx/__init__.py:253-292.  ``seed`` may be a list: one image per seed is denoised in a
         single batched step loop (data-parallel sharding hands each rank a list)."""
-        if image_path is not None:
-            raise NotImplementedError("img2img (VAE encoder) is outside this build's scope (SURVEY.md §8f f4)")
         seed = int(time.time()) if seed is None else seed
         seeds = list(seed) if isinstance(seed, (list, tuple)) else [seed]
         logger.info(f"Seed: {seeds}")
-        denoise = 1.0
         x_T = self.get_empty_latent(*latent_size)
-        noise = np.concatenate([self.get_noise(s, x_T) for s in seeds], axis=0)
+        if image_path is None:
+            denoise = 1.0
+            x_T = np.repeat(x_T, len(seeds), axis=0) if len(seeds) > 1 else x_T
+        else:
+            # img2img (mlx/__init__.py:270-277): the encoded image, one posterior sample per seed
+            x_T = torch.cat([self.latent_format.process_in(self.encode_image_to_latents(image_path, seed=s)) for s in seeds], 0)
+            x_T = x_T.cpu().numpy()
+        noise = np.concatenate([self.get_noise(s, x_T[:1]) for s in seeds], axis=0)
         sigmas = self.get_sigmas(self.sampler, num_steps)
         sigmas = sigmas[int(num_steps * (1 - denoise)):]
         extra_args = {
@@ -303,6 +325,36 @@ class DiffusionPipeline:
 
     def get_sigmas(self, sampler, num_steps: int):
         return get_sigmas(sampler, num_steps)
+
+    def read_image(self, image_path):
+        """mlx/__init__.py:536-551: RGB in [-1, 1], NHWC float32 [1,H,W,3]; sizes are cut down to a
+        multiple of 64 with a LANCZOS resize.  ``image_path`` may also be a PIL image or an HWC uint8 array."""
+        from PIL import Image
+        if isinstance(image_path, np.ndarray):
+            img = Image.fromarray(image_path)
+        elif isinstance(image_path, Image.Image):
+            img = image_path
+        else:
+            img = Image.open(image_path)
+        W, H = (dim - dim % 64 for dim in (img.width, img.height))
+        if W != img.width or H != img.height:
+            logger.warning(f"Warning: image shape is not divisible by 64, downsampling to {W}x{H}")
+            img = img.resize((W, H), Image.LANCZOS)
+        arr = np.array(img)
+        if arr.ndim == 2:
+            arr = np.repeat(arr[:, :, None], 3, axis=2)
+        arr = (arr[:, :, :3].astype(np.float32) / 255) * 2 - 1.0
+        return torch.from_numpy(np.ascontiguousarray(arr[None])).to(self.device)
+
+    def encode_image_to_latents(self, image_path, seed):
+        """mlx/__init__.py:586-594: mean + std * noise of the VAE posterior, NHWC float32 on the device."""
+        self.load_vae_encoder()
+        image = self.read_image(image_path)
+        moments = self.encoder.encode(image)
+        b, h, w, _ = moments.shape
+        mean_like = np.empty((b, h, w, self.vae_encoder_config.out_channels // 2), dtype=np.float32)
+        noise = torch.from_numpy(self.get_noise(seed, mean_like)).to(self.device)
+        return self.encoder.sample(moments, noise)
 
     def get_empty_latent(self, *shape):
         return np.ones([1, *shape, 16], dtype=np.float32) * np.float32(0.0609)

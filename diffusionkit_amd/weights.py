@@ -146,6 +146,50 @@ def synth_vae_weights(cfg: VAEDecoderConfig, seed: int = 4321, device="cpu", dty
     return I.out
 
 
+def synth_vae_encoder_weights(cfg, seed: int = 8765, device="cpu", dtype=torch.bfloat16, shapes_only=False) -> Dict[str, Tensor]:
+    """Random weights keyed like the reference VAEEncoder module tree (vae.py:404-454)."""
+    I = _Init(device, seed, dtype, shapes_only)
+
+    def conv(prefix, o, i):
+        I.normal(prefix + ".weight", (o, 3, 3, i))
+        I.normal(prefix + ".bias", (o,))
+
+    def norm(prefix, c):
+        I.normal(prefix + ".weight", (c,), mean=1.0)
+        I.normal(prefix + ".bias", (c,))
+
+    def resnet(prefix, cin, cout):
+        norm(prefix + ".norm1", cin)
+        conv(prefix + ".conv1", cout, cin)
+        norm(prefix + ".norm2", cout)
+        conv(prefix + ".conv2", cout, cout)
+        if cin != cout:
+            I.linear(prefix + ".conv_shortcut", cout, cin)
+
+    boc = list(cfg.block_out_channels)
+    conv("conv_in", boc[0], cfg.in_channels)
+    cprev = boc[0]
+    for i, cout in enumerate(boc):
+        for rr in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{i}.resnets.{rr}", cprev if rr == 0 else cout, cout)
+        if i < len(boc) - 1:
+            conv(f"down_blocks.{i}.downsample", cout, cout)
+        cprev = cout
+    cm = boc[-1]
+    resnet("mid_blocks.0", cm, cm)
+    norm("mid_blocks.1.group_norm", cm)
+    for n in ("query_proj", "key_proj", "value_proj", "out_proj"):
+        I.linear(f"mid_blocks.1.{n}", cm, cm)
+    resnet("mid_blocks.2", cm, cm)
+    norm("conv_norm_out", cm)
+    conv("conv_out", cfg.out_channels, cm)
+    return I.out
+
+
+def vae_encoder_weight_shapes(cfg) -> Dict[str, tuple]:
+    return synth_vae_encoder_weights(cfg, shapes_only=True)
+
+
 # ---------------------------------------------------------------------------------------------
 # packing
 # ---------------------------------------------------------------------------------------------
@@ -226,7 +270,8 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
     return out
 
 
-def pack_vae(cfg: VAEDecoderConfig, w: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+def pack_vae(cfg, w: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+    """Decoder or encoder half: conv weights [O,3,3,I] -> [O, 9*I] (conv_in zero-padded to I = 64)."""
     dev = torch.device(device)
     out: Dict[str, Tensor] = {}
     for k, t in w.items():

@@ -88,7 +88,9 @@ typedef struct dk_conv_desc {
   const void* zeros;/* >= 128 bytes of zeros on the device (padding taps)            */
   int32_t B, H, W, C, O; /* H, W are OUTPUT sizes                                     */
   int32_t ldy, ldr;
-  int32_t upsample; /* 1: conv over the nearest-x2 upsampling of x (vae.py:20-25,146) */
+  int32_t upsample; /* 1: conv over the nearest-x2 upsampling of x (vae.py:20-25,146);
+                     * 2: stride-2 conv over x = [B, 2H, 2W, C] padded by one zero row / column at the
+                     *    bottom / right (the encoder's downsample, vae.py:141-143)          */
   int32_t epilogue;
 } dk_conv_desc;
 
@@ -217,6 +219,20 @@ size_t dk_vae_workspace_bytes(const dk_vae* v, int32_t batch, int32_t latent_h, 
 int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int32_t latent_h, int32_t latent_w,
                   float* image_f32, uint8_t* image_u8, void* raw_bf16, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* VAEEncoder.__call__ (vae.py:456-467) on a dk_vae created with the encoder's configuration and
+ * bound to its module names (conv_in, down_blocks.{i}.resnets.{r}, down_blocks.{i}.downsample,
+ * mid_blocks.{0,1,2}, conv_norm_out, conv_out).  image: f32 [B,H,W,in_channels] in [-1,1]
+ * (read_image, __init__.py:536-551); moments (mean | logvar, __init__.py:588-589):
+ * bf16 [B,H/8,W/8,ldm] (ldm multiple of 4, >= out_channels) and / or f32 [B,H/8,W/8,out_channels]. */
+size_t dk_vae_encoder_workspace_bytes(const dk_vae* v, int32_t batch, int32_t image_h, int32_t image_w);
+int dk_vae_encode(dk_vae* v, const float* image, int32_t batch, int32_t image_h, int32_t image_w,
+                  void* moments_bf16, int32_t ldm, float* moments_f32, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* encode_image_to_latents tail (__init__.py:589-594):
+ * latent = mean + exp(0.5 * clip(logvar, -30, 20)) * noise, f32 [n_pixels, latent_channels] */
+int dk_latent_sample_f32(const void* moments_bf16, int32_t ldm, const float* noise, float* latent,
+                         int64_t n_pixels, int32_t latent_channels, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference times phases with time.time(),

@@ -64,6 +64,12 @@ LATENT_FORMAT = {  # mlx/__init__.py:736-747 (scale_factor, shift_factor)
 }
 
 
+def process_in(latent: Tensor, fmt: str) -> Tensor:
+    """LatentFormat.process_in (mlx/__init__.py:729-730)"""
+    scale, shift = LATENT_FORMAT[fmt]
+    return (latent - shift) * scale
+
+
 def process_out(latent: Tensor, fmt: str) -> Tensor:
     """LatentFormat.process_out (mlx/__init__.py:732-733)"""
     scale, shift = LATENT_FORMAT[fmt]
@@ -101,13 +107,37 @@ def sample_euler(model: OracleMMDiT, x: Tensor, sigmas: Tensor, conditioning: Te
     return x
 
 
+def read_image_array(rgb_u8: np.ndarray) -> Tensor:
+    """read_image (mlx/__init__.py:536-551) for an HWC uint8 array whose sides are multiples of 64
+    (the resize branch is host-side PIL code, not restated): RGB in [-1, 1], [1,H,W,3] fp32."""
+    assert rgb_u8.shape[0] % 64 == 0 and rgb_u8.shape[1] % 64 == 0
+    return torch.from_numpy((rgb_u8[:, :, :3].astype(np.float32) / 255) * 2 - 1.0)[None]
+
+
+def encode_image_to_latents(encoder, image: Tensor, seed: int) -> Tensor:
+    """mlx/__init__.py:586-594: posterior sample with the numpy noise of ``seed`` (shape of the mean)."""
+    from .vae import sample_latent
+    hidden = encoder(image)
+    _, h, w, c2 = hidden.shape
+    return sample_latent(hidden, get_noise(seed, h, w, c2 // 2))
+
+
 def denoise_latents(model: OracleMMDiT, conditioning: Tensor, pooled: Tensor, num_steps: int,
                     cfg_weight: float, latent_size, seed: int, shift: float, flux: bool,
-                    act: Prec, trace: Optional[list] = None) -> Tensor:
-    """DiffusionPipeline.denoise_latents (mlx/__init__.py:253-292), image_path=None."""
-    x_T = get_empty_latent(*latent_size)
+                    act: Prec, trace: Optional[list] = None, init_latent: Optional[Tensor] = None,
+                    denoise: float = 1.0) -> Tensor:
+    """DiffusionPipeline.denoise_latents (mlx/__init__.py:253-292).  ``init_latent`` = the output of
+    encode_image_to_latents for img2img (image_path given), else the empty latent and denoise = 1."""
+    fmt = "flux" if flux else "sd3"
+    if init_latent is None:
+        x_T = get_empty_latent(*latent_size)
+        denoise = 1.0
+    else:
+        x_T = process_in(init_latent, fmt)
+        latent_size = tuple(x_T.shape[1:3])
     noise = get_noise(seed, *latent_size)
     sigmas = get_sigmas(shift, flux, num_steps)
+    sigmas = sigmas[int(num_steps * (1 - denoise)):]
     noise_scaled = sigmas[0] * noise + (1.0 - sigmas[0]) * x_T  # sampler.py:41-42
     latent = sample_euler(model, noise_scaled, sigmas, conditioning, pooled, cfg_weight, act, trace)
     return process_out(latent, "flux" if flux else "sd3")

@@ -1,4 +1,4 @@
-"""CPU ORACLE (test infrastructure, NOT product code) -- latent-decode VAE.
+"""CPU ORACLE (test infrastructure, NOT product code) -- latent-decode VAE (+ the img2img encoder half).
 
 PyTorch-CPU restatement of the reference's VAEDecoder
 (python/src/diffusionkit/mlx/vae.py:20-25 upsample_nearest, :28-57 Attention,
@@ -100,6 +100,46 @@ class OracleVAEDecoder:
                 taps[f"up{j}"] = x.clone()
         x = silu(self._gn(x, "conv_norm_out"), P)
         return self._conv(x, "conv_out")
+
+
+def conv2d_s2_pad_br_nhwc(x: Tensor, w: Tensor, b: Optional[Tensor], P: Prec) -> Tensor:
+    """EncoderDecoderBlock2D downsample (vae.py:141-143): mx.pad(x, [(0,0),(0,1),(0,1),(0,0)]) then
+    nn.Conv2d(k3, stride 2, padding 0)."""
+    xp = F.pad(x.permute(0, 3, 1, 2), (0, 1, 0, 1))
+    y = F.conv2d(xp, w.permute(0, 3, 1, 2), b, stride=2, padding=0)
+    return P.r(y.permute(0, 2, 3, 1))
+
+
+class OracleVAEEncoder(OracleVAEDecoder):
+    """VAEEncoder (vae.py:404-467); shares the block restatements of the decoder oracle."""
+
+    def __call__(self, x: Tensor, taps: Optional[dict] = None) -> Tensor:
+        """x: [B,H,W,3] in [-1,1] -> hidden [B,H/8,W/8,32] (mean | logvar)."""
+        c, P = self.cfg, self.P
+        x = self._conv(P.r(x), "conv_in")
+        n = len(c.block_out_channels)
+        for i in range(n):
+            for r in range(c.layers_per_block):
+                x = self._resnet(x, f"down_blocks.{i}.resnets.{r}")
+            if (f"down_blocks.{i}.downsample.weight") in self.w:
+                x = conv2d_s2_pad_br_nhwc(x, self.w[f"down_blocks.{i}.downsample.weight"],
+                                          self.w[f"down_blocks.{i}.downsample.bias"], P)
+            if taps is not None:
+                taps[f"down{i}"] = x.clone()
+        x = self._resnet(x, "mid_blocks.0")
+        x = self._attention(x, "mid_blocks.1")
+        x = self._resnet(x, "mid_blocks.2")
+        x = silu(self._gn(x, "conv_norm_out"), P)
+        return self._conv(x, "conv_out")
+
+
+def sample_latent(hidden: Tensor, noise: Tensor) -> Tensor:
+    """encode_image_to_latents tail (mlx/__init__.py:588-594): split mean / logvar on the channel axis,
+    clip logvar to [-30, 20], latent = mean + exp(0.5 * logvar) * noise (fp32: the reference's encoder
+    output is fp32 because the image enters as fp32)."""
+    mean, logvar = hidden.float().chunk(2, dim=-1)
+    logvar = torch.clip(logvar, -30.0, 20.0)
+    return mean + torch.exp(0.5 * logvar) * noise.float()
 
 
 def decode_latents_to_image(decoder: OracleVAEDecoder, x_t: Tensor) -> Tensor:

@@ -13,11 +13,13 @@ import numpy as np
 import pytest
 import torch
 
-from diffusionkit_amd.config import (FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, tiny_flux, tiny_sd3, tiny_vae)
-from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
+from diffusionkit_amd.config import (FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, VAEEncoderConfig, tiny_flux, tiny_sd3, tiny_vae,
+                                     tiny_vae_encoder)
+from diffusionkit_amd.weights import (pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_encoder_weights,
+                                      synth_vae_weights)
 from oracle import pipeline as op
 from oracle.mmdit import OracleMMDiT, Prec
-from oracle.vae import OracleVAEDecoder, decode_latents_to_image, to_uint8
+from oracle.vae import OracleVAEDecoder, OracleVAEEncoder, decode_latents_to_image, to_uint8
 from tests._util import BF, bf16r, max_abs, psnr, randn, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -201,8 +203,6 @@ def test_generate_image_api(dev):
     assert np.array_equal(np.asarray(img), np.asarray(img2))  # deterministic for a fixed seed
     with pytest.raises(AssertionError):
         pipe.generate_image("x", latent_size=(7, 8))
-    with pytest.raises(NotImplementedError):
-        pipe.denoise_latents(None, None, image_path="x.png")
     fl = pipe.decode_latents_to_image(torch.zeros(1, 8, 8, 16, device=dev))
     assert fl.shape == (1, 64, 64, 3) and float(fl.min()) >= 0.0 and float(fl.max()) <= 1.0
 
@@ -276,3 +276,74 @@ def test_vae_production_channels(dev):
     res = {n: OracleVAEDecoder(vcfg, wf, P)(bf16r(z)) for n, P in (("fp32", Prec()), ("emu", Prec(BF)))}
     yardstick_ok(raw[..., :3].float(), res["emu"], res["fp32"], "vae prod")
     assert psnr(torch.clip(res["fp32"] / 2 + 0.5, 0, 1), img) > 35.0
+
+
+# ---- img2img: VAE encoder + denoise-truncated schedule ------------------------
+def _test_image(H, W, seed=0):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([(yy * 255 // H), (xx * 255 // W), ((yy + xx) * 255 // (H + W))], -1)
+    return np.clip(base + rng.randint(-20, 20, size=(H, W, 3)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (128, 64)])
+def test_vae_encode_tiny(dev, hw):
+    """VAEEncoder.__call__ (vae.py:456-467) vs the oracle: conv_in on the 3-channel image, stride-2
+    downsamples, mid attention, moments."""
+    from diffusionkit_amd.engine import VAEEncoderEngine
+    cfg = tiny_vae_encoder()
+    named = synth_vae_encoder_weights(cfg, seed=8765)
+    eng = VAEEncoderEngine(cfg, pack_vae(cfg, named, dev))
+    img = op.read_image_array(_test_image(*hw))
+    img = torch.cat([img, -img], 0)
+    hid = eng(img.to(dev))
+    assert hid.shape == (2, hw[0] // 8, hw[1] // 8, 32)
+    wf = {k: v.float() for k, v in named.items()}
+    res = {n: OracleVAEEncoder(cfg, wf, P)(img) for n, P in (("fp32", Prec()), ("emu", Prec(BF)))}
+    yardstick_ok(hid.float(), res["emu"], res["fp32"], "vae encoder moments")
+
+
+def test_img2img_pipeline_tiny(dev, tmp_path):
+    """generate_image(image_path=, denoise=) (mlx/__init__.py:270-277,536-551,586-594): image file ->
+    posterior sample -> process_in -> truncated schedule -> Euler loop, vs the oracle restatement."""
+    from PIL import Image
+    from diffusionkit_amd.pipeline import FluxPipeline
+    cfg, ecfg = tiny_flux(), tiny_vae_encoder()
+    pipe = FluxPipeline(w16=True, a16=True, mmdit_config=cfg, vae_config=tiny_vae(), vae_encoder_config=ecfg, device=dev, text_len=16)
+    rgb = _test_image(64, 128, seed=1)
+    path = str(tmp_path / "init.png")
+    Image.fromarray(rgb).save(path)
+    text = randn(1, 16, cfg.token_level_text_embed_dim, seed=7)
+    pooled = randn(1, cfg.pooled_text_embed_dim, seed=8)
+    lat, iter_time = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=4, cfg_weight=0.0,
+                                          latent_size=(8, 16), seed=2, image_path=path, denoise=0.5)
+    assert len(iter_time) == 2 and lat.shape == (1, 8, 16, 16)  # 4 steps * denoise 0.5 -> last 2 steps
+    wf = {k: v.float() for k, v in synth_mmdit_weights(cfg, seed=1234).items()}
+    ewf = {k: v.float() for k, v in synth_vae_encoder_weights(ecfg, seed=1234 + 2).items()}
+    res = {}
+    for pname, P in (("fp32", Prec()), ("emu", Prec(BF))):
+        z0 = op.encode_image_to_latents(OracleVAEEncoder(ecfg, ewf, P), op.read_image_array(rgb), seed=2)
+        res[pname] = op.denoise_latents(OracleMMDiT(cfg, wf, P), text, pooled, 4, 0.0, (8, 16), 2, 1.0, True, Prec(BF),
+                                        init_latent=z0, denoise=0.5)
+    yardstick_ok(lat, res["emu"], res["fp32"], "img2img latent")
+    assert psnr(res["fp32"], lat) > 35.0
+    # denoise = 1.0 with an image still starts from pure noise at sigma_max (noise_scaling, sampler.py:41-42)
+    img, log = pipe.generate_image("x", num_steps=2, latent_size=(8, 16), seed=2, image_path=path, denoise=1.0, verbose=False)
+    assert img.size == (128, 64) and len(log["denoising"]["iter_time"]) == 2
+    # a size that is not a multiple of 64 is resized down like the reference (LANCZOS)
+    big = Image.fromarray(_test_image(100, 150, seed=2))
+    assert pipe.read_image(big).shape == (1, 64, 128, 3)
+
+
+def test_vae_encoder_production_channels(dev):
+    """Production encoder plan (128,256,512,512; 2 resnets/level, 3 -> 32 channels) on a 128x128 image."""
+    from diffusionkit_amd.engine import VAEEncoderEngine
+    cfg = VAEEncoderConfig()
+    named = synth_vae_encoder_weights(cfg, seed=99)
+    eng = VAEEncoderEngine(cfg, pack_vae(cfg, named, dev))
+    img = op.read_image_array(_test_image(128, 128, seed=3))
+    hid = eng(img.to(dev))
+    assert hid.shape == (1, 16, 16, 32)
+    wf = {k: v.float() for k, v in named.items()}
+    res = {n: OracleVAEEncoder(cfg, wf, P)(img) for n, P in (("fp32", Prec()), ("emu", Prec(BF)))}
+    yardstick_ok(hid.float(), res["emu"], res["fp32"], "vae encoder prod")

@@ -215,6 +215,36 @@ def test_conv3x3(dev, B, H, W, C, O, ups, res):
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
 
 
+@pytest.mark.parametrize("B,H,W,C,O", [(1, 16, 16, 64, 128), (2, 8, 24, 128, 64), (1, 64, 32, 64, 64)])
+def test_conv3x3_stride2_downsample(dev, B, H, W, C, O):
+    """EncoderDecoderBlock2D downsample (vae.py:141-143): pad bottom / right by one, conv k3 s2 p0."""
+    from diffusionkit_amd import ops
+    x = randn(B, H, W, C, seed=24)
+    w = randn(O, 3, 3, C, seed=25, scale=0.05)
+    b = randn(O, seed=26, scale=0.1)
+    y = ops.conv3x3(g(x, dev), g(w, dev), g(b, dev), downsample=True)
+    ref = ov.conv2d_s2_pad_br_nhwc(x, w, b, Prec())
+    assert y.shape == ref.shape == (B, H // 2, W // 2, O)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+
+
+def test_latent_sample(dev):
+    """encode_image_to_latents tail (__init__.py:588-594) incl. the logvar clip."""
+    from diffusionkit_amd.config import tiny_vae_encoder
+    from diffusionkit_amd.engine import VAEEncoderEngine
+    from diffusionkit_amd.weights import pack_vae, synth_vae_encoder_weights
+    cfg = tiny_vae_encoder()
+    eng = VAEEncoderEngine(cfg, pack_vae(cfg, synth_vae_encoder_weights(cfg), dev))
+    mom = randn(2, 4, 6, 32, seed=27, scale=1.0)
+    mom[0, 0, 0, 16] = 1000.0   # logvar clipped to 20
+    mom[0, 0, 1, 17] = -1000.0  # logvar clipped to -30
+    noise = randn(2, 4, 6, 16, seed=28)
+    got = eng.sample(g(mom, dev), noise.to(dev))
+    ref = ov.sample_latent(bf16r(mom), noise)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    assert torch.allclose(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
 # ---- attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 128, 128), (1, 3, 200, 128), (2, 4, 333, 64), (1, 24, 1088, 128),
                                      (2, 24, 589 + 64, 64)])

@@ -10,8 +10,8 @@ import pytest
 import torch
 
 from diffusionkit_amd import model_io as mio
-from diffusionkit_amd.config import tiny_flux, tiny_sd3, tiny_vae
-from diffusionkit_amd.weights import synth_mmdit_weights, synth_vae_weights
+from diffusionkit_amd.config import tiny_flux, tiny_sd3, tiny_vae, tiny_vae_encoder
+from diffusionkit_amd.weights import synth_mmdit_weights, synth_vae_encoder_weights, synth_vae_weights
 
 
 def to_bfl_flux(w, cfg):
@@ -161,6 +161,55 @@ def test_vae_checkpoint_round_trip(tmp_path):
         path = os.path.join(tmp_path, "vae.safetensors")
         save_file(to_compvis_vae(w, cfg, prefix), path)
         same(mio.load_vae_decoder_checkpoint(path, cfg), w)
+
+
+def to_compvis_vae_encoder(w, prefix):
+    """reference VAEEncoder names -> CompVis autoencoder ``encoder.*`` layout (inverse of
+    vae_encoder_state_dict_adjustments, model_io.py:489-563)."""
+    oihw = lambda t: t.permute(0, 3, 1, 2)
+    sd = {}
+    for k, t in w.items():
+        stem, leaf = k.rsplit(".", 1)
+        wt = leaf == "weight"
+        if stem in ("conv_in", "conv_out"):
+            sd[k] = oihw(t) if wt else t
+        elif stem == "conv_norm_out":
+            sd[f"norm_out.{leaf}"] = t
+        elif stem.startswith("mid_blocks.1."):
+            part = stem.split(".")[-1]
+            name = {"group_norm": "norm", "query_proj": "q", "key_proj": "k", "value_proj": "v", "out_proj": "proj_out"}[part]
+            sd[f"mid.attn_1.{name}.{leaf}"] = t[:, :, None, None] if (wt and part != "group_norm") else t
+        elif stem.startswith("mid_blocks."):
+            idx, part = stem.split(".")[1], stem.split(".")[2]
+            sd[f"mid.block_{1 if idx == '0' else 2}.{part}.{leaf}"] = oihw(t) if (wt and "conv" in part) else t
+        elif ".resnets." in stem:
+            _, j, _, r, part = stem.split(".")
+            if part == "conv_shortcut":
+                sd[f"down.{j}.block.{r}.nin_shortcut.{leaf}"] = t[:, :, None, None] if wt else t
+            else:
+                sd[f"down.{j}.block.{r}.{part}.{leaf}"] = oihw(t) if (wt and "conv" in part) else t
+        elif stem.endswith(".downsample"):
+            sd[f"down.{stem.split('.')[1]}.downsample.conv.{leaf}"] = oihw(t) if wt else t
+        else:
+            raise AssertionError(k)
+    out = {prefix + k: v.contiguous() for k, v in sd.items()}
+    out["decoder.conv_in.weight"] = torch.zeros(2, 2)  # the other half of the autoencoder file: ignored
+    return out
+
+
+def test_vae_encoder_checkpoint_round_trip(tmp_path):
+    """f4: the img2img encoder half (model_io.py:489-563)."""
+    from safetensors.torch import save_file
+    cfg = tiny_vae_encoder()
+    w = synth_vae_encoder_weights(cfg, seed=8)
+    for prefix in ("encoder.", "first_stage_model.encoder."):
+        path = os.path.join(tmp_path, "vae_enc.safetensors")
+        save_file(to_compvis_vae_encoder(w, prefix), path)
+        same(mio.load_vae_encoder_checkpoint(path, cfg), w)
+    bad = to_compvis_vae_encoder(w, "encoder.")
+    del bad["encoder.down.0.downsample.conv.bias"]
+    with pytest.raises(mio.CheckpointError):
+        mio.load_vae_encoder_checkpoint(bad, cfg)
 
 
 def test_loader_fails_loudly():
