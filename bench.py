@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "tiny"])
+    ap.add_argument("--batch", type=int, default=1,
+                    help="images per rank and step, denoised in one batched step loop (FLUX workloads; default 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -158,12 +160,18 @@ def main():
     cond = torch.randn(rows, S_t, cfg.token_level_text_embed_dim, generator=g).to(dev, torch.bfloat16)
     pooled = torch.randn(rows, cfg.pooled_text_embed_dim, generator=g).to(dev, torch.bfloat16)
 
+    B = args.batch
+    assert B >= 1 and (B == 1 or rows == 1), "--batch > 1 is offered for the FLUX workloads (one conditioning row per image)"
+    if B > 1:
+        cond, pooled = cond.repeat(B, 1, 1), pooled.repeat(B, 1)
+
     denoise_ms, vae_ms = [], []
 
     def one_image(seed):
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        lat, _ = pipe.denoise_latents(cond, pooled, num_steps=num_steps, cfg_weight=cfg_weight, latent_size=latent, seed=seed)
+        lat, _ = pipe.denoise_latents(cond, pooled, num_steps=num_steps, cfg_weight=cfg_weight, latent_size=latent,
+                                      seed=seed if B == 1 else [seed * B + b for b in range(B)])
         e1.record()
         _, u8, _ = pipe.decoder.decode(lat)
         e2.record()
@@ -195,7 +203,7 @@ def main():
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events on the launch stream ----
     S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
-    step_flops = mmdit_step_flops(cfg, S_t, S_i, rows)
+    step_flops = mmdit_step_flops(cfg, S_t, S_i, rows)  # per image
     image_flops = num_steps * step_flops + vae_flops(vcfg, *latent)
     roofline = None
     if not args.no_roofline and rank == 0:
@@ -222,11 +230,11 @@ def main():
             "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "flops_per_launch": work / max(n, 1),
-            "gemm_ms_per_image": round(ms / args.steps, 2),
+            "gemm_ms_per_image": round(ms / args.steps / B, 2),
             "attention": {"achieved": round(stats["attention"][1] / max(stats["attention"][0], 1e-9) / 1e9, 1),
-                          "ms_per_image": round(stats["attention"][0] / args.steps, 2), "launches": stats["attention"][2]},
+                          "ms_per_image": round(stats["attention"][0] / args.steps / B, 2), "launches": stats["attention"][2]},
             "conv": {"achieved": round(stats["conv"][1] / max(stats["conv"][0], 1e-9) / 1e9, 1),
-                     "ms_per_image": round(stats["conv"][0] / args.steps, 2), "launches": stats["conv"][2]},
+                     "ms_per_image": round(stats["conv"][0] / args.steps / B, 2), "launches": stats["conv"][2]},
             "instrumented_ms_per_step": round(instr / args.steps * 1e3, 2),
             "method": "HIP events around every launch on the launch stream, replay of the timed region",
         }
@@ -236,7 +244,7 @@ def main():
         cpu = cpu_baseline(cfg, S_t, S_i, num_steps, image_flops, step_flops)
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = world * args.steps * B / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "images/sec (whole node) FLUX.1-schnell 1024x1024 4-step" if args.workload == "flux-schnell-1024"
@@ -245,12 +253,12 @@ def main():
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
             "config": {"workload": f"{args.workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
-                                   f"text tokens {S_t}, batch 1 image per GPU per step, + VAE decode to uint8",
+                                   f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8",
                        "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
             "denoise_ms_per_step": round(float(np.mean(denoise_ms)) / num_steps, 2),
             "vae_decode_ms": round(float(np.mean(vae_ms)), 2),
             "algorithmic_tflop_per_image": round(image_flops / 1e12, 2),
-            "mfma_roofline_frac_whole_path": round(image_flops * args.steps / elapsed / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "mfma_roofline_frac_whole_path": round(image_flops * args.steps * B / elapsed / (PEAK_BF16_TFLOPS * 1e12), 4),
             "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
