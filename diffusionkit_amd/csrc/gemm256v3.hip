@@ -37,6 +37,12 @@
 #define DK_V3_PH1 2
 #define DK_V3_STR 4
 #endif
+#ifndef DK_V3_SKEW
+#define DK_V3_SKEW 1
+#endif
+#ifndef DK_V3_SKEW_R
+#define DK_V3_SKEW_R 8  // MFMA slot of a step behind which the skewed wave group issues its fragment reads
+#endif
 // pieces per step, in issue order: the step behind the tile barrier (S3), then S0, S1, S2 of the next K-tile
 #ifndef DK_V3_N3
 #define DK_V3_N3 4
@@ -173,9 +179,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   asm volatile("s_waitcnt lgkmcnt(" #N ")" \
                : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]))
 // 16 MFMAs acc[nf][MB + mf] += W[nf] . A[mf], with NG DMA pieces (TILE, G0 ..) in front of slots PH, PH+4, ... when ON
-#define DK_MMG(WSET, ASET, MB, TILE, G0, NG, PH, ON)                                                              \
+#define DK_MMG(WSET, ASET, MB, TILE, G0, NG, PH, ON) DK_MMGR(WSET, ASET, MB, TILE, G0, NG, PH, ON, 0, 16)
+#define DK_MMGR(WSET, ASET, MB, TILE, G0, NG, PH, ON, E0, E1)                                                     \
   do {                                                                                                            \
-    _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                           \
+    _Pragma("unroll") for (int e_ = (E0); e_ < (E1); ++e_) {                                                           \
       if (!(DK_V3_ABL & 1) && (NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) % DK_V3_STR) == 0 && ((e_ - (PH)) / DK_V3_STR) < (NG)) \
         issue_piece((TILE), (G0) + ((e_ - (PH)) / DK_V3_STR));                                                    \
       acc[e_ >> 2][(MB) + (e_ & 3)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##WSET[e_ >> 2], xf##ASET[e_ & 3], \
@@ -206,6 +213,36 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_MMG(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk);                                                              \
   }
 
+// Skewed form (DK_V3_SKEW, default): the same K-tile for the second wave of each SIMD with its fragment reads in the
+// MIDDLE of every 16-MFMA step instead of in front of it, so that the two waves of a SIMD do not run their
+// read / wait sections at the same time (+1.5-2 % in the lab).
+#define DK_LOOP_SKEW(PH, R)                                                                                    \
+  for (int i = 0; i < nk; ++i) {                                                                               \
+    constexpr bool in_loop = true;                                                                             \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                    \
+    const bool on1 = i >= 1 && i + 1 < nk;                                                                     \
+    DK_WAIT8(0, wf0, xf0);                                                                                     \
+    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1, 0, R);                                                \
+    DK_RDA_HI(1, bo, 0);                                                                                       \
+    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1, R, 16);                                               \
+    DK_WAIT4(0, xf1);                                                                                          \
+    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, 0, R);                                                             \
+    DK_RDW(1, bo, 1);                                                                                          \
+    DK_RDA_LO(0, bo, 1);                                                                                       \
+    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, R, 16);                                                            \
+    DK_WAIT8(0, wf1, xf0);                                                                                     \
+    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, 0, R);                                                             \
+    DK_RDA_HI(1, bo, 1);                                                                                       \
+    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, R, 16);                                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
+    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                        \
+    asm volatile("" ::: "memory");                                                                             \
+    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk, 0, R);                                                \
+    DK_RDW(0, bo ^ KT_BYTES, 0);                                                                               \
+    DK_RDA_LO(0, bo ^ KT_BYTES, 0);                                                                            \
+    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk, R, 16);                                               \
+  }
+
   {
     bf16x8 wf0[4], wf1[4], xf0[4], xf1[4];
     issue_tile(0);
@@ -223,12 +260,30 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     if (wm == 0) {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
+#if DK_V3_SKEW == 2
+      if (wn & 1) {
+        DK_LOOP_SKEW(DK_V3_PH0, 4)
+      } else {
+        DK_LOOP(DK_V3_PH0)
+      }
+#else
       DK_LOOP(DK_V3_PH0)
+#endif
       DK_WAIT8(0, wf0, xf0);
     } else {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
+#if DK_V3_SKEW == 2  /* lab: four read positions, by SIMD parity as well */
+      if (wn & 1) {
+        DK_LOOP_SKEW(DK_V3_PH1, 12)
+      } else {
+        DK_LOOP_SKEW(DK_V3_PH1, 8)
+      }
+#elif DK_V3_SKEW
+      DK_LOOP_SKEW(DK_V3_PH1, DK_V3_SKEW_R)
+#else
       DK_LOOP(DK_V3_PH1)
+#endif
       DK_WAIT8(0, wf0, xf0);
     }
   }
@@ -239,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_WAIT4
 #undef DK_WAIT8
 #undef DK_MMG
+#undef DK_MMGR
 #undef DK_LOOP
+#undef DK_LOOP_SKEW
 
   // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
   // All waves passed the last loop barrier after their final ds_read, so the ring is free.
