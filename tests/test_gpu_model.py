@@ -9,6 +9,8 @@ and final latents / images must reach PSNR >= 35 dB against the fp32 oracle (the
 torch<->CoreML bar, tests/torch2coreml/test_mmdit.py:27; its MLX image gate is 20 dB,
 tests/mlx/test_diffusion_pipeline.py:20).
 """
+from dataclasses import replace
+
 import numpy as np
 import pytest
 import torch
@@ -68,7 +70,9 @@ def forward_case(cfg, dev, B, Hl, Wl, S_t, timesteps, step):
 
 
 @pytest.mark.parametrize("name,cfg,B", [("flux", tiny_flux(), 1), ("flux_b2", tiny_flux(), 2), ("sd3", tiny_sd3(), 2),
-                                        ("sd3_b1", tiny_sd3(), 1)])
+                                        ("sd3_b1", tiny_sd3(), 1),
+                                        # SD3.5-large shape class (config.py:74-76): QK-norm without RoPE, learned pos-emb
+                                        ("sd35", replace(tiny_sd3(depth=3, heads=6), use_qk_norm=True), 2)])
 def test_mmdit_forward_tiny(dev, name, cfg, B):
     ts = [1000.0, 752.0, 500.0]
     eng, out, res = forward_case(cfg, dev, B, 8, 12, 20, ts, 1)
