@@ -46,6 +46,7 @@ int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
 int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream);  // gemm256.hip
 extern int g_dk_gemm_mode;
 extern int g_dk_v2_sched;
+extern int g_dk_v3_split;  // gemm256v3.hip: remainder-wave K split (-1 auto, 0 off, 1 whenever possible)
 // stream-K form (persistent grid, fp32 slabs + flags in a caller-owned workspace whose last 4 KiB
 // -- the flag region -- must be zero before the first launch; kernels leave it zero)
 size_t dk_streamk_workspace_bytes();

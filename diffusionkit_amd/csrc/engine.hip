@@ -24,6 +24,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "gemm_sched") == 0) { g_dk_v2_sched = value; return 0; }
+  if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }

@@ -55,7 +55,11 @@ struct SkArgs {
 // 16-byte write-through (sc1) store: the slab reaches memory without an agent-scope release fence
 // (buffer_wbl2 would write back every dirty line of the XCD's L2, other workgroups' C tiles included)
 __device__ __forceinline__ void store_sc1_b128(float* ptr, f32x4 v) {
+#ifdef DK_SK_PLAINST  /* lab: timing with plain write-back stores (hand-off not guaranteed) */
+  *(f32x4*)ptr = v;
+#else
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+#endif
 }
 
 __device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -368,7 +372,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v2_kernel(GemmParams pa, Gem
             }
           }
         }
+#ifndef DK_SK_NOACQ  /* lab: timing without the agent-scope acquire (results may be stale) */
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         __syncthreads();
       }
 #pragma unroll 4

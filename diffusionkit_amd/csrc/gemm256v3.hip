@@ -22,6 +22,7 @@
 //
 // C / D layout of the swapped-operand MFMA (A-operand = W fragment, B-operand = activation fragment):
 // lane holds output row m = mf*16 + (lane & 15), columns n = nf*16 + 4*(lane >> 4) + {0..3}.
+#include <cstring>
 #include <type_traits>
 
 #include "dk_kernels.h"
@@ -61,7 +62,41 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef __attribute__((address_space(3))) char lds_char;
 
-__global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b) {
+// Remainder split (dk_launch_gemm256v3): the tiles beyond the last full wave of the CUs -- n_rem < #CU of them --
+// are cut along K into S pieces with the SAME cut points for every tile (so that the workgroups that run at the
+// same time still walk K in step and share A / W panels in L2): piece 0 = [0, ks) is the tile's finisher, pieces
+// 1 .. S-1 share [ks, nk) and are producers (fp32 partial tile -> slab, flag).  Block order = dispatch order:
+// full tiles, then the n_rem finishers, then the producers; a finisher only waits at its very end, and at least
+// #CU - n_rem CUs are never held by finishers, so producers always get to run.
+struct SplitArgs {
+  float* slabs;     // [n_rem * (S - 1)][256 * 256] fp32 row-major tile images
+  unsigned* flags;  // [n_rem * (S - 1)], zero between launches (reset by the finisher)
+  unsigned* error_word;
+  int n_dp;         // full tiles (multiple of 8); 0 <= n_dp <= tiles
+  int n_rem;        // split tiles = tiles - n_dp (0: no split)
+  int S;            // pieces per split tile
+  int ks;           // K-tiles of the finisher piece
+};
+#define SLAB_FLOATS (256 * 256)
+
+// 16-byte write-through (sc1) store: the slab reaches memory without an agent-scope release fence
+__device__ __forceinline__ void v3_store_sc1_b128(float* ptr, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+
+// position of block `bid` inside the XCD-contiguous order of the `count` blocks that start at block `base`
+// (hardware places block b on XCD b & 7): neighbouring positions share an XCD, hence an L2
+__device__ __forceinline__ int xcd_contiguous(int bid, int base, int count) {
+  const int x = bid & 7;
+  int start = 0;
+  for (int y = 0; y < x; ++y) {
+    const int first = (y - base) & 7;  // offset of XCD y's first block inside the group
+    start += first < count ? (count - first + 7) >> 3 : 0;
+  }
+  return start + ((bid - base) >> 3);
+}
+
+__global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, SplitArgs sp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
   const int tid = threadIdx.x;
@@ -70,13 +105,29 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, q = lane >> 4;
 
-  const int nk = pa.K / BK;
-  const int G = tiles_a + tiles_b;
-  int tile;  // XCD-contiguous workgroup index: neighbouring tiles share an L2
+  const int nk_full = pa.K / BK;
+  int tile;       // XCD-contiguous tile index: neighbouring tiles share an L2
+  int k0 = 0, nk = nk_full;  // this workgroup's K-tile range [k0, k0 + nk)
+  int piece = -1;            // -1 full tile, 0 finisher of a split tile, >= 1 producer
+  int rt = 0;                // index of the split tile
   {
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, qq = G >> 3, r = G & 7;
-    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+    if (bid < sp.n_dp || sp.n_rem == 0) {
+      tile = xcd_contiguous(bid, 0, sp.n_rem == 0 ? tiles_a + tiles_b : sp.n_dp);
+    } else {
+      const int j = bid - sp.n_dp;
+      piece = j / sp.n_rem;
+      const int base = sp.n_dp + piece * sp.n_rem;
+      rt = xcd_contiguous(bid, base, sp.n_rem);
+      tile = sp.n_dp + rt;
+      if (piece == 0) {
+        nk = sp.ks;
+      } else {
+        const int rest = nk_full - sp.ks, np = sp.S - 1;
+        k0 = sp.ks + rest * (piece - 1) / np;
+        nk = sp.ks + rest * piece / np - k0;
+      }
+    }
   }
   const bool second = tile >= tiles_a;
   const GemmParams& p = second ? pb : pa;
@@ -114,8 +165,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
     }
   }
-  const char* gA = (const char*)p.A;
-  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2;
+  const char* gA = (const char*)p.A + (size_t)k0 * (BK * 2);
+  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2 + (size_t)k0 * (BK * 2);
   const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
 
   // LDS-DMA in the buffer form: SGPR resource (base, 4 GiB range) + 32-bit lane offset + scalar offset -- no 64-bit
@@ -318,6 +369,28 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
   const int rrow = lane >> 3, rchunk = lane & 7;   // read-back: 8 rows x 8 chunks of 16 B per instruction
 
+  // split tile: a producer stores its fp32 partial tile to its slab; the finisher first waits for every producer of
+  // the tile (hand-off per guide G16: write-through slab stores, vmcnt(0) in every wave, barrier, one relaxed
+  // agent-scope flag store; consumer: relaxed poll, one agent-scope acquire, barrier, plain loads)
+  const int n_prod = sp.S - 1;
+  float* const my_slab = piece >= 1 ? sp.slabs + (size_t)(rt * n_prod + piece - 1) * SLAB_FLOATS : nullptr;
+  if (piece == 0 && !(DK_V3_ABL & 16)) {
+    if (tid == 0) {
+      for (int pp = 0; pp < n_prod; ++pp) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sp.flags + rt * n_prod + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 24)) {
+            __hip_atomic_store(sp.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
@@ -374,7 +447,19 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
           if (epi == DK_EPI_GATE_RES)
             for (g_rem += 8; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
-        const f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        if (piece >= 0) {  // split tile
+          const size_t slab_idx = (size_t)(wm * 128 + row) * 256 + wn * 64 + ni * 32 + rchunk * 4;
+          if (piece >= 1) {
+            if (!(DK_V3_ABL & 8)) v3_store_sc1_b128(my_slab + slab_idx, a);  // (lab: 8 = producers do not store)
+            continue;
+          }
+          for (int pp = 0; pp < ((DK_V3_ABL & 16) ? 0 : n_prod); ++pp) {  // (lab: 16 = finishers neither wait nor read)
+            const f32x4 o = *(const f32x4*)(sp.slabs + (size_t)(rt * n_prod + pp) * SLAB_FLOATS + slab_idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += o[e];
+          }
+        }
         float vv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
@@ -409,6 +494,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     else
       rows(std::false_type{});
   }
+  if (piece >= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(sp.flags + rt * n_prod + piece - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (piece == 0) {
+    __syncthreads();  // every wave has read the slabs
+    if (tid == 0)
+      for (int pp = 0; pp < n_prod; ++pp) __hip_atomic_store(sp.flags + rt * n_prod + pp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 bool dk_gemm256v3_eligible(const GemmParams& p) {
@@ -424,13 +518,63 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
   return a_rows * (size_t)p.lda * 2 < (1ull << 32) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
 }
 
+// dk_tune_set("gemm_split", v): 0 never (default), 1 whenever possible, -1 by the cost model below.  Kernel lab
+// (profiles/r01_gemm_lab.md): every workgroup carries ~18 us of fixed cost (launch, first DMA, tail) and a CU runs
+// its K-tiles ~20 % slower when all 256 CUs are busy than when 192 are, so filling the idle CUs of a remainder wave
+// gains at most a few percent on the longest-K shape and loses on the others -- kept as a tested option only.
+int g_dk_v3_split = 0;
+
+// How the tiles beyond the last full wave of the CUs are cut along K (see SplitArgs).  n_rem == 0: no split.
+struct SplitPlan {
+  int n_dp, n_rem, S, ks;
+};
+static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
+  SplitPlan none{tiles, 0, 1, nk};
+  if (!have_ws || g_dk_v3_split == 0 || n_cu < 16) return none;
+  const int G = n_cu & ~7;
+  const int T = tiles % G;
+  if (T == 0) return none;
+  const int E = G - T;
+  int S, ks, t_steps;  // t_steps: K-tile steps until the split wave is done
+  if (T > G / 2) {  // one producer piece per tile, c = ceil(T / E) of them in turn on each of the E spare CUs
+    S = 2;
+    const int c = (T + E - 1) / E;
+    ks = (nk * c + c) / (c + 1);  // ~ nk * c / (c + 1), rounded up: the finishers must not end before the producers
+    if (ks > nk - 1) ks = nk - 1;
+    t_steps = ks > c * (nk - ks) ? ks : c * (nk - ks);
+  } else {  // S equal pieces per tile, one CU each
+    S = G / T < 4 ? G / T : 4;
+    ks = (nk + S - 1) / S;
+    t_steps = ks;
+  }
+  if (S < 2 || ks < 1 || nk - ks < S - 1 || T * (S - 1) > 256) return none;
+  // a K-tile step costs about 1.45 us; splitting costs a slab write + read and a flag round trip per tile
+  if (g_dk_v3_split < 0 && (nk - t_steps) * 1.45 < 14.0) return none;
+  return SplitPlan{tiles - T, T, S, ks};
+}
+
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream) {
   static bool attr_set = false;
+  static int n_cu = 0;
   if (!attr_set) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    int dev = 0;
+    DK_CHECK_HIP(hipGetDevice(&dev));
+    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
-  hipLaunchKernelGGL(dk_gemm256v3_kernel, dim3(tiles_a + tiles_b), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b);
+  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_streamk_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0;
+  const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
+  SplitArgs sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.n_dp = pl.n_dp; sp.n_rem = pl.n_rem; sp.S = pl.S; sp.ks = pl.ks;
+  if (pl.n_rem > 0) {
+    sp.slabs = (float*)p.workspace;
+    sp.flags = (unsigned*)((char*)p.workspace + (size_t)256 * SLAB_FLOATS * 4);
+    sp.error_word = sp.flags + 512;
+  }
+  const int grid = pl.n_dp + pl.n_rem * pl.S;
+  hipLaunchKernelGGL(dk_gemm256v3_kernel, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
   return 0;
 }
 

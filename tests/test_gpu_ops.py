@@ -215,6 +215,41 @@ def test_conv3x3(dev, B, H, W, C, O, ups, res):
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 768, 640, "gate_res"),     # 12 tiles: 4 equal pieces per tile
+                                       (1178, 512, 384, "bias"),         # ragged M, 10 tiles
+                                       (3328, 2560, 256, "gelu"),        # 130 tiles > half the CUs: finisher + 1 producer
+                                       (4352, 3072, 512, "gate_res")])   # 204 tiles, 4 producer pieces in turn per spare CU
+def test_gemm_v3_remainder_split(dev, M, N, K, epi):
+    """dk_tune_set("gemm_split", 1): the tiles beyond the last full wave of the CUs are cut along K into a
+    finisher piece and producer pieces (fp32 slabs + flags in the caller's workspace).  Same results as
+    the unsplit kernel up to the fp32 summation order; the flag region must be left zero."""
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=50), randn(N, K, seed=51, scale=0.05), randn(N, seed=52, scale=0.1)
+    res, gate = randn(M, N, seed=53), randn(1, N, seed=54)
+    acc = bf16r(x @ w.t() + b)
+    ws = ops.gemm_workspace(dev)
+    kw = {}
+    if epi == "gelu":
+        kw, ref = dict(epilogue=ops.DK_EPI_BIAS_GELU), om.gelu_erf(acc, Prec())
+    elif epi == "gate_res":
+        kw, ref = dict(epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev), gate_seg_len=M), res + bf16r(gate * acc)
+    else:
+        ref = acc
+    try:
+        ops.tune("gemm", 9)
+        ops.tune("gemm_split", 1)
+        y = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
+        ops.tune("gemm_split", 0)
+        y0 = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
+    finally:
+        ops.tune("gemm", -1)
+        ops.tune("gemm_split", 0)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+    assert max_abs(y0.float(), y.float()) <= 0.02 * float(ref.abs().max()) + 1e-2  # a bf16 ulp where the summation order differs
+    assert float((y0.float() != y.float()).float().mean()) < 0.02
+    assert int(ws[-4096:].sum()) == 0
+
+
 @pytest.mark.parametrize("B,H,W,C,O", [(1, 16, 16, 64, 128), (2, 8, 24, 128, 64), (1, 64, 32, 64, 64)])
 def test_conv3x3_stride2_downsample(dev, B, H, W, C, O):
     """EncoderDecoderBlock2D downsample (vae.py:141-143): pad bottom / right by one, conv k3 s2 p0."""
