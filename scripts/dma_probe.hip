@@ -60,6 +60,62 @@ __global__ __launch_bounds__(512, 2) void probe(const char* __restrict__ src, si
   out[blockIdx.x * 512 + tid] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 }
 
+// GEMM-like sharing: the 32 workgroups of an XCD form a 4 x 8 tile block; the 8 workgroups of a block row read the
+// same "A panel" K-slab (32 KiB per iteration), the 4 of a block column the same "W panel" K-slab, all in step
+// (STAG = 0) or with their K position rotated by STAG * (index inside the sharing group) iterations.
+template <int STAG>
+__global__ __launch_bounds__(512, 2) void probe_shared(const char* __restrict__ src, unsigned* __restrict__ out, int iters, int nk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;  // 32 workgroups per XCD
+  const int row = cu >> 3, col = cu & 7;                  // 4 x 8 block
+  const size_t panel = (size_t)nk * 32768;                // one panel = nk K-slabs of 32 KiB
+  const char* pa = src + (size_t)(xcd * 12 + row) * panel;
+  const char* pw = src + (size_t)(xcd * 12 + 4 + col) * panel;
+  for (int it = 0; it < iters; ++it) {
+    const int ka = (it + STAG * col) % nk, kw = (it + STAG * row) % nk;
+    const unsigned ring = (it & 1) * 65536 + wave * 8192;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pa + (size_t)ka * 32768 + wave * 4096 + j * 1024 + lane * 16),
+                                       (lds_ptr_t)((lds_char*)smem + ring + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pw + (size_t)kw * 32768 + wave * 4096 + j * 1024 + lane * 16),
+                                       (lds_ptr_t)((lds_char*)smem + ring + 4096 + j * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the workgroups of a block stay in step like the GEMM's do
+  }
+  out[blockIdx.x * 512 + tid] = *(const unsigned*)(smem + tid * 4);
+}
+
+// The same sharing, with the GEMM's real addressing: a panel is 256 (A) / 256 (W) rows at a row stride of `ld` bytes and a
+// K-tile is 128 bytes of every row (each DMA instruction = 8 rows x 128 B), instead of one contiguous 32 KiB slab.
+__global__ __launch_bounds__(512, 2) void probe_shared_rows(const char* __restrict__ src, unsigned* __restrict__ out, int iters, int nk, size_t ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  const int row = cu >> 3, col = cu & 7;
+  const size_t panel = (size_t)256 * ld;  // 256 rows
+  const char* pa = src + (size_t)(xcd * 12 + row) * panel;
+  const char* pw = src + (size_t)(xcd * 12 + 4 + col) * panel;
+  const size_t lane_off = (size_t)(lane >> 3) * ld + (lane & 7) * 16;  // 8 rows x 8 chunks of 16 B
+  for (int it = 0; it < iters; ++it) {
+    const int k = it % nk;
+    const unsigned ring = (it & 1) * 65536 + wave * 8192;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t r0 = (size_t)(wave * 32 + j * 8) * ld + (size_t)k * 128;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pa + r0 + lane_off), (lds_ptr_t)((lds_char*)smem + ring + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pw + r0 + lane_off), (lds_ptr_t)((lds_char*)smem + ring + 4096 + j * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  out[blockIdx.x * 512 + tid] = *(const unsigned*)(smem + tid * 4);
+}
+
 int main(int argc, char** argv) {
   const int iters = 4096, nblk = 256;
   void *src, *out;
@@ -90,6 +146,50 @@ int main(int argc, char** argv) {
              bytes / nblk / (best * 1e-3) / 1e9, bytes / nblk / (best * 1e-3) / 2.1e9, best);
     }
     CK(hipFree(src));
+  }
+  {
+    const int nk = 48, it2 = 48 * 64;
+    const size_t span = (size_t)8 * 12 * nk * 32768;  // 8 XCDs x 12 panels
+    CK(hipMalloc(&src, span));
+    CK(hipMemset(src, 1, span));
+    for (int stag = 0; stag < 3; ++stag) {
+      float best = 1e30f;
+      for (int r = 0; r < 4; ++r) {
+        CK(hipEventRecord(e0));
+        if (stag == 0) hipLaunchKernelGGL(probe_shared<0>, dim3(nblk), dim3(512), 131072, 0, (const char*)src, (unsigned*)out, it2, nk);
+        if (stag == 1) hipLaunchKernelGGL(probe_shared<1>, dim3(nblk), dim3(512), 131072, 0, (const char*)src, (unsigned*)out, it2, nk);
+        if (stag == 2) hipLaunchKernelGGL(probe_shared<3>, dim3(nblk), dim3(512), 131072, 0, (const char*)src, (unsigned*)out, it2, nk);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      const double bytes = (double)nblk * it2 * 65536.0;
+      printf("GEMM-like sharing (4 x 8 tile block per XCD, panels of %d K-slabs), K rotation %d: %7.2f TB/s  (%.1f B/clk/CU at 2.1 GHz, %.2f us per 64 KiB K-tile)\n",
+             nk, stag == 2 ? 3 : stag, bytes / (best * 1e-3) / 1e12, bytes / nblk / (best * 1e-3) / 2.1e9, best * 1e3 / it2);
+    }
+    CK(hipFree(src));
+    for (size_t ld : {(size_t)6144, (size_t)6144 + 256, (size_t)30720, (size_t)128 * 48}) {
+      const size_t span2 = (size_t)8 * 12 * 256 * ld;
+      CK(hipMalloc(&src, span2));
+      CK(hipMemset(src, 1, span2));
+      const int nk2 = (int)(ld / 128) < 48 ? (int)(ld / 128) : 48;
+      float best = 1e30f;
+      for (int r = 0; r < 4; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(probe_shared_rows, dim3(nblk), dim3(512), 131072, 0, (const char*)src, (unsigned*)out, it2, nk2, ld);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      const double bytes = (double)nblk * it2 * 65536.0;
+      printf("GEMM-like sharing, row-strided K-tiles (row stride %zu B): %7.2f TB/s  (%.1f B/clk/CU at 2.1 GHz, %.2f us per 64 KiB K-tile)\n", ld,
+             bytes / (best * 1e-3) / 1e12, bytes / nblk / (best * 1e-3) / 2.1e9, best * 1e3 / it2);
+      CK(hipFree(src));
+    }
   }
   return 0;
 }
