@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "tiny"])
+    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "flux-dev-1024", "tiny"])
     ap.add_argument("--batch", type=int, default=1,
                     help="images per rank and step, denoised in one batched step loop (FLUX workloads; default 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +129,11 @@ def main():
     if args.workload == "flux-schnell-1024":
         cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 4, 0.0, 1.0, 256, 1
+    elif args.workload == "flux-dev-1024":
+        # BASELINE configs[3] shape (50 steps, 512 text tokens) with bf16 weights: the fp8-weight variant is not built;
+        # like the reference (quirk Q7) FLUX.1-dev runs without its guidance embedding
+        cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-dev"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 0.0, 1.0, 512, 1
     elif args.workload == "sd3-medium-1024":
         cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 5.0, 3.0, 589, 2
