@@ -4,7 +4,8 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_lab/obj
 for f in gemm gemm256 gemm256sk gemm256v3 attention attention2 elementwise vae_ops profile engine; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDK_LAB_ABLATIONS -c diffusionkit_amd/csrc/$f.hip -o build_lab/obj/$f.o &
+  EXTRA=""; [ "$f" = attention2 ] && EXTRA="-fno-honor-nans"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDK_LAB_ABLATIONS $EXTRA -c diffusionkit_amd/csrc/$f.hip -o build_lab/obj/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_lab/libdk_hip.so build_lab/obj/*.o
