@@ -16,17 +16,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even f32 -> bf16 (NaN not special-cased: the hot path never produces NaN
-// from finite inputs; inf stays inf).
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even f32 -> bf16 through the hardware conversion (v_cvt_pk_bf16_f32 on gfx950: one
+// instruction per PAIR of values instead of a 3-4 instruction integer sequence per value -- the GEMM tails were
+// bound by that VALU work)
+typedef __bf16 dk_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const dk_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ void unpack2bf(uint32_t v, float& lo, float& hi) {
   lo = __uint_as_float(v << 16);

@@ -490,11 +490,12 @@ int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk,
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
   const GemmParams& pb = p2 ? *p2 : p;
-  if (!streamk && g_dk_v2_sched == 3)
+  const bool v3_ok = dk_gemm256v3_eligible(p) && (!p2 || dk_gemm256v3_eligible(*p2));  // (16-byte aligned outputs)
+  if (!streamk && g_dk_v2_sched == 3 && v3_ok)
     dk_launch_gemm256v3_raw(p, pb, tiles_a, tiles_b, stream);
   else if (streamk)
     hipLaunchKernelGGL((dk_gemm256v2_kernel<true, 0>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
-  else if (g_dk_v2_sched == 1)
+  else if (g_dk_v2_sched == 1 || g_dk_v2_sched == 3)
     hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 1>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);
   else if (g_dk_v2_sched == 2)
     hipLaunchKernelGGL((dk_gemm256v2_kernel<false, 2>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sk);

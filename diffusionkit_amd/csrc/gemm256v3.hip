@@ -367,7 +367,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128 : 0;
   const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
   const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
-  const int rrow = lane >> 3, rchunk = lane & 7;   // read-back: 8 rows x 8 chunks of 16 B per instruction
+  // read-back: a lane takes 8 consecutive columns (two 16-byte chunks) of one row, 4 lanes a 32-column row of the
+  // image, 16 rows per step -- one 16-byte global store per lane and step (8-byte stores are issue-bound: half as
+  // many instructions, guide T21).  Image swizzle chunk ^ ((row >> 1) & 7): conflict-free for the staging writes
+  // (16 rows x one chunk per 16 lanes) and for these reads (4 rows x 4 even / odd chunks per 16 lanes).
+  const int rrow = lane >> 2, rc2 = (lane & 3) * 2;
 
   // split tile: a producer stores its fp32 partial tile to its slab; the finisher first waits for every producer of
   // the tile (hand-off per guide G16: write-through slab stores, vmcnt(0) in every wave, barrier, one relaxed
@@ -391,35 +395,34 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     __syncthreads();
   }
 
+  auto unpack8 = [](const uint4 v, float* f) {
+    unpack2bf(v.x, f[0], f[1]);
+    unpack2bf(v.y, f[2], f[3]);
+    unpack2bf(v.z, f[4], f[5]);
+    unpack2bf(v.w, f[6], f[7]);
+  };
+
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
+  for (int ni = 0; ni < (((DK_V3_ABL & 64) && p.alpha != -1234.5f) ? 0 : 2); ++ni) {  // (lab: 64 = no tail at run time)
     // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) {
         const int row = mf * 16 + l15;
-        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ (row & 7)) << 4)) = acc[ni * 2 + nf][mf];
+        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
       }
     // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
-    const int col = n0 + wn * 64 + ni * 32 + rchunk * 4;      // column of the GEMM (bias, gate, residual)
-    const int ocol = ncol0 + wn * 64 + ni * 32 + rchunk * 4;  // column inside the output it goes to
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gate4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      const uint2 bb = *(const uint2*)(p.bias + col);
-      unpack2bf(bb.x, bias4[0], bias4[1]);
-      unpack2bf(bb.y, bias4[2], bias4[3]);
-    }
+    const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual)
+    const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && piece < 1) unpack8(*(const uint4*)(p.bias + col), bias8);
     // the row loop is instantiated twice -- tile-uniform maps (FAST) or a per-lane walk through the maps -- so that
     // the common case keeps its short body (one v_add per address, batched loads)
     auto rows = [&](auto fast_c) {
       constexpr bool FAST = decltype(fast_c)::value;
-      if (FAST && epi == DK_EPI_GATE_RES) {
-        const uint2 gg = *(const uint2*)(gate_row + col);
-        unpack2bf(gg.x, gate4[0], gate4[1]);
-        unpack2bf(gg.y, gate4[2], gate4[3]);
-      }
-      // row walk of the slow path: (segment, row inside it) of this lane's current row in each map; 8 rows per step
+      if (FAST && epi == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
+      // row walk of the slow path: (segment, row inside it) of this lane's current row in each map; 16 rows per step
       int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
       if (!FAST) {
         const int ms = mrow0 + rrow;
@@ -428,65 +431,72 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
 #pragma unroll 4
-      for (int itr = 0; itr < 16; ++itr) {
-        const int row = itr * 8 + rrow;  // row inside the wave's 128-row block
+      for (int itr = 0; itr < 8; ++itr) {
+        const int row = itr * 16 + rrow;  // row inside the wave's 128-row block
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
         bool valid = true;
         if (!FAST) {
           valid = mrow0 + row < p.M;
           crow = (size_t)c_seg * p.c_seg_stride + c_rem;
           rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
-          if (epi == DK_EPI_GATE_RES && valid) {
-            const uint2 gg = *(const uint2*)(p.gate + (size_t)g_seg * p.gate_stride + col);
-            unpack2bf(gg.x, gate4[0], gate4[1]);
-            unpack2bf(gg.y, gate4[2], gate4[3]);
-          }
-          for (c_rem += 8; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
+          if (epi == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
+          for (c_rem += 16; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
           if (has_res)
-            for (r_rem += 8; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
+            for (r_rem += 16; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
           if (epi == DK_EPI_GATE_RES)
-            for (g_rem += 8; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
+            for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
-        f32x4 a = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        const unsigned sw = (unsigned)((row >> 1) & 7);
+        f32x4 a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
+        f32x4 a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
         if (piece >= 0) {  // split tile
-          const size_t slab_idx = (size_t)(wm * 128 + row) * 256 + wn * 64 + ni * 32 + rchunk * 4;
+          const size_t slab_idx = (size_t)(wm * 128 + row) * 256 + wn * 64 + ni * 32 + rc2 * 4;
           if (piece >= 1) {
-            if (!(DK_V3_ABL & 8)) v3_store_sc1_b128(my_slab + slab_idx, a);  // (lab: 8 = producers do not store)
+            if (!(DK_V3_ABL & 8)) {  // (lab: 8 = producers do not store)
+              v3_store_sc1_b128(my_slab + slab_idx, a0);
+              v3_store_sc1_b128(my_slab + slab_idx + 4, a1);
+            }
             continue;
           }
           for (int pp = 0; pp < ((DK_V3_ABL & 16) ? 0 : n_prod); ++pp) {  // (lab: 16 = finishers neither wait nor read)
-            const f32x4 o = *(const f32x4*)(sp.slabs + (size_t)(rt * n_prod + pp) * SLAB_FLOATS + slab_idx);
+            const float* sl = sp.slabs + (size_t)(rt * n_prod + pp) * SLAB_FLOATS + slab_idx;
+            const f32x4 o0 = *(const f32x4*)sl, o1 = *(const f32x4*)(sl + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] += o[e];
+            for (int e = 0; e < 4; ++e) a0[e] += o0[e], a1[e] += o1[e];
           }
         }
-        float vv[4];
+        float vv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = round_bf16(a[e] * p.alpha + bias4[e]);
+        for (int e = 0; e < 4; ++e) {
+          vv[e] = round_bf16(a0[e] * p.alpha + bias8[e]);
+          vv[4 + e] = round_bf16(a1[e] * p.alpha + bias8[4 + e]);
+        }
         if (epi == DK_EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] = gelu_erf_f(vv[e]);
+          for (int e = 0; e < 8; ++e) vv[e] = gelu_erf_f(vv[e]);
         } else if (epi == DK_EPI_BIAS_SILU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] = silu_f(vv[e]);
+          for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
         } else if (has_res) {
-          uint2 rr = make_uint2(0u, 0u);
-          if (FAST || valid) rr = *(const uint2*)(p.res + rrow_phys * (size_t)p.ldr + col);
-          float r4[4];
-          unpack2bf(rr.x, r4[0], r4[1]);
-          unpack2bf(rr.y, r4[2], r4[3]);
+          uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
+          float r8[8];
+          unpack8(rr, r8);
           if (epi == DK_EPI_GATE_RES) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] = r4[e] + round_bf16(gate4[e] * vv[e]);
+            for (int e = 0; e < 8; ++e) vv[e] = r8[e] + round_bf16(gate8[e] * vv[e]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] += r4[e];
+            for (int e = 0; e < 8; ++e) vv[e] += r8[e];
           }
         }
-        uint2 o2;
-        o2.x = pack2bf(vv[0], vv[1]);
-        o2.y = pack2bf(vv[2], vv[3]);
-        if (FAST || valid) *(uint2*)(Cb + crow * (size_t)ldcb + ocol) = o2;
+        uint4 o4;
+        o4.x = pack2bf(vv[0], vv[1]);
+        o4.y = pack2bf(vv[2], vv[3]);
+        o4.z = pack2bf(vv[4], vv[5]);
+        o4.w = pack2bf(vv[6], vv[7]);
+        // (lab: 32 = the C stores sit behind a condition that is false at run time -- the work stays, the traffic goes)
+        if (((DK_V3_ABL & 32) ? p.alpha == -1234.5f : true) && (FAST || valid)) *(uint4*)(Cb + crow * (size_t)ldcb + ocol) = o4;
       }
     };
     if (fast)
@@ -506,13 +516,16 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 }
 
 bool dk_gemm256v3_eligible(const GemmParams& p) {
-  if (p.conv || p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldc % 4 != 0) return false;
-  if (p.n_split % 256 != 0 || (p.n_split > 0 && (p.C2 == nullptr || p.ldc2 % 4 != 0 || p.n_split >= p.N))) return false;
+  if (p.conv || p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldc % 8 != 0) return false;
+  if (p.n_split % 256 != 0 || (p.n_split > 0 && (p.C2 == nullptr || p.ldc2 % 8 != 0 || p.n_split >= p.N))) return false;
   if (p.a_seg_len <= 0 || p.c_seg_len <= 0) return false;
   const bool res1 = p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES;
   const bool res2 = p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES);
-  if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 4 != 0)) return false;
+  if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 8 != 0)) return false;
   if ((p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES)) && (p.gate == nullptr || p.gate_seg_len <= 0)) return false;
+  // 16-byte accesses in the tail
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (!al16(p.C) || !al16(p.C2) || !al16(p.res) || !al16(p.bias) || !al16(p.gate) || (p.gate != nullptr && p.gate_stride % 8 != 0)) return false;
   // 32-bit byte offsets on the DMA side: the A rows this problem touches and 8 rows of W
   const size_t a_rows = (size_t)((p.M - 1) / p.a_seg_len) * p.a_seg_stride + (size_t)((p.M - 1) % p.a_seg_len) + 1;
   return a_rows * (size_t)p.lda * 2 < (1ull << 32) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
