@@ -38,6 +38,9 @@
 #define DK_V3_PH1 2
 #define DK_V3_STR 4
 #endif
+#ifndef DK_V3_NT_STORE
+#define DK_V3_NT_STORE 0  // lab: C leaves through non-temporal stores
+#endif
 #ifndef DK_V3_SKEW
 #define DK_V3_SKEW 1
 #endif
@@ -496,7 +499,14 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         o4.z = pack2bf(vv[4], vv[5]);
         o4.w = pack2bf(vv[6], vv[7]);
         // (lab: 32 = the C stores sit behind a condition that is false at run time -- the work stays, the traffic goes)
-        if (((DK_V3_ABL & 32) ? p.alpha == -1234.5f : true) && (FAST || valid)) *(uint4*)(Cb + crow * (size_t)ldcb + ocol) = o4;
+        if (((DK_V3_ABL & 32) ? p.alpha == -1234.5f : true) && (FAST || valid)) {
+#if DK_V3_NT_STORE
+          const u32x4 ov = {o4.x, o4.y, o4.z, o4.w};
+          __builtin_nontemporal_store(ov, (u32x4*)(Cb + crow * (size_t)ldcb + ocol));
+#else
+          *(uint4*)(Cb + crow * (size_t)ldcb + ocol) = o4;
+#endif
+        }
       }
     };
     if (fast)
