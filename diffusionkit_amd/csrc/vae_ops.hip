@@ -27,8 +27,7 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   const bf16_t* base = x + (size_t)b * HW * C + cg * 8;
-  for (long pix = p0 + pl; pix < p1; pix += ppi) {
-    const u32x4 raw = *(const u32x4*)(base + (size_t)pix * C);
+  auto accumulate = [&](const u32x4 raw) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a0, a1;
@@ -36,7 +35,19 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
       s[2 * e] += a0; q[2 * e] += a0 * a0;
       s[2 * e + 1] += a1; q[2 * e + 1] += a1 * a1;
     }
+  };
+  long pix = p0 + pl;
+  for (; pix + 3 * ppi < p1; pix += 4 * ppi) {  // four independent 16-byte loads in flight per lane
+    const u32x4 r0 = *(const u32x4*)(base + (size_t)pix * C);
+    const u32x4 r1 = *(const u32x4*)(base + (size_t)(pix + ppi) * C);
+    const u32x4 r2 = *(const u32x4*)(base + (size_t)(pix + 2 * ppi) * C);
+    const u32x4 r3 = *(const u32x4*)(base + (size_t)(pix + 3 * ppi) * C);
+    accumulate(r0);
+    accumulate(r1);
+    accumulate(r2);
+    accumulate(r3);
   }
+  for (; pix < p1; pix += ppi) accumulate(*(const u32x4*)(base + (size_t)pix * C));
   // red[stat][pl][channel]: channel = cg*8 + e
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -87,45 +98,63 @@ int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, flo
   return 0;
 }
 
-// y = [silu]( bf16( (x - mean) * rstd * gamma + beta ) )
+// y = [silu]( bf16( (x - mean) * rstd * gamma + beta ) ), evaluated as x * scale[c] + shift[c] with the per-channel
+// fp32 pair (scale = rstd * gamma, shift = beta - mean * scale) built once per workgroup in LDS: the kernel is a
+// pure stream (one 16-byte load and store per 8 values, no integer divisions in the element loop)
+#define GN_APPLY_U 4
 __global__ __launch_bounds__(256) void dk_gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long HW, int C, int G,
                                                           const float* __restrict__ mean_rstd, const bf16_t* __restrict__ gamma,
-                                                          const bf16_t* __restrict__ beta, int do_silu, long total_chunks) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total_chunks) return;
-  const int cpr = C / 8;
-  const int cg = (int)(i % cpr);
-  const long pix = i / cpr;  // global pixel index over batch
-  const int b = (int)(pix / HW);
+                                                          const bf16_t* __restrict__ beta, int do_silu) {
+  __shared__ float tab[2 * 2048];  // scale[C] | shift[C]
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
-  const u32x4 raw = *(const u32x4*)(x + (size_t)i * 8);
-  const u32x4 gr = *(const u32x4*)(gamma + cg * 8);
-  const u32x4 br = *(const u32x4*)(beta + cg * 8);
-  u32x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float a0, a1, g0, g1, b0, b1;
-    unpack2bf(raw[e], a0, a1);
-    unpack2bf(gr[e], g0, g1);
-    unpack2bf(br[e], b0, b1);
-    const int c0 = cg * 8 + 2 * e;
-    const float* mr0 = mean_rstd + ((size_t)b * G + c0 / cpg) * 2;
-    const float* mr1 = mean_rstd + ((size_t)b * G + (c0 + 1) / cpg) * 2;
-    float y0 = round_bf16((a0 - mr0[0]) * mr0[1] * g0 + b0);
-    float y1 = round_bf16((a1 - mr1[0]) * mr1[1] * g1 + b1);
-    if (do_silu) {
-      y0 = silu_f(y0);
-      y1 = silu_f(y1);
-    }
-    o[e] = pack2bf(y0, y1);
+  for (int c = tid; c < C; c += 256) {
+    const float* mr = mean_rstd + ((size_t)b * G + c / cpg) * 2;
+    const float sc = mr[1] * bf2f(gamma[c]);
+    tab[c] = sc;
+    tab[C + c] = bf2f(beta[c]) - mr[0] * sc;
   }
-  *(u32x4*)(y + (size_t)i * 8) = o;
+  __syncthreads();
+  const unsigned cpr = (unsigned)(C / 8);                      // 16-byte chunks per pixel
+  const unsigned total = (unsigned)HW * cpr;                   // chunks of this batch row (< 2^31, checked by the launcher)
+  const bf16_t* xb = x + (size_t)b * HW * C;
+  bf16_t* yb = y + (size_t)b * HW * C;
+  const unsigned i0 = blockIdx.x * (256u * GN_APPLY_U) + tid;
+  u32x4 raw[GN_APPLY_U];
+#pragma unroll
+  for (int u = 0; u < GN_APPLY_U; ++u) {
+    const unsigned i = i0 + u * 256u;
+    if (i < total) raw[u] = *(const u32x4*)(xb + (size_t)i * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < GN_APPLY_U; ++u) {
+    const unsigned i = i0 + u * 256u;
+    if (i >= total) continue;
+    const unsigned c0 = (i & (cpr - 1)) * 8;  // cpr is a power of two (checked by the launcher)
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a0, a1;
+      unpack2bf(raw[u][e], a0, a1);
+      float y0 = round_bf16(a0 * tab[c0 + 2 * e] + tab[C + c0 + 2 * e]);
+      float y1 = round_bf16(a1 * tab[c0 + 2 * e + 1] + tab[C + c0 + 2 * e + 1]);
+      if (do_silu) {
+        y0 = silu_f(y0);
+        y1 = silu_f(y1);
+      }
+      o[e] = pack2bf(y0, y1);
+    }
+    *(u32x4*)(yb + (size_t)i * 8) = o;
+  }
 }
 int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,
                               const bf16_t* gamma, const bf16_t* beta, int do_silu, hipStream_t stream) {
-  const long total = (long)B * HW * (C / 8);
-  hipLaunchKernelGGL(dk_gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, HW, C, G, mean_rstd,
-                     gamma, beta, do_silu, total);
+  DK_REQUIRE(C <= 2048 && C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "channels must be 8 * 2^k <= 2048");
+  DK_REQUIRE((double)HW * (C / 8) < 2147483648.0, "one batch row must hold < 2^31 16-byte chunks");
+  const long total = HW * (C / 8);
+  const long per_wg = 256L * GN_APPLY_U;
+  hipLaunchKernelGGL(dk_gn_apply_kernel, dim3((unsigned)((total + per_wg - 1) / per_wg), B), dim3(256), 0, stream, x, y, HW, C, G,
+                     mean_rstd, gamma, beta, do_silu);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
