@@ -108,15 +108,17 @@ __global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(bf16_t* __restrict
                                                               float eps, const float* __restrict__ rope, int row_seg_len,
                                                               int row_seg_stride, int pos_off) {
   constexpr int LPI = D / 8;  // lanes per item
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long item = gid / LPI;
+  // 32-bit index arithmetic (rows * 2H * LPI < 2^31, checked by the launcher): 64-bit divisions cost more VALU
+  // work than the 16 bytes this lane moves
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned item = gid / LPI;
   const int sub = (int)(gid % LPI);
-  const long nitems = (long)rows * 2 * H;
+  const unsigned nitems = (unsigned)rows * 2u * (unsigned)H;
   const bool active = item < nitems;
-  const long it = active ? item : nitems - 1;
-  const int m = (int)(it / (2 * H));
-  const int rem = (int)(it % (2 * H));
-  const int which = rem / H, head = rem % H;
+  const unsigned it = active ? item : nitems - 1;
+  const int m = (int)(it / (2u * (unsigned)H));
+  const int rem = (int)(it - (unsigned)m * 2u * (unsigned)H);
+  const int which = rem >= H ? 1 : 0, head = rem - which * H;
   const int seg = m / row_seg_len, pos_in = m % row_seg_len;
   bf16_t* ptr = qkv + (size_t)(seg * row_seg_stride + pos_in) * ld + (which ? k_off : q_off) + head * D + sub * 8;
   const u32x4 raw = *(const u32x4*)ptr;
@@ -166,6 +168,7 @@ int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, 
   DK_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0, "alignment");
   if (qw == nullptr && rope == nullptr) return 0;
   const long threads = (long)rows * 2 * H * (D / 8);
+  DK_REQUIRE(threads < (1L << 31) - 256, "qk_norm_rope: rows * 2H * D/8 must stay below 2^31");
   dim3 grid((unsigned)((threads + 255) / 256)), block(256);
   if (D == 128)
     hipLaunchKernelGGL(dk_qk_norm_rope_kernel<128>, grid, block, 0, stream, qkv, ld, q_off, k_off, rows, H, qw, kw, eps, rope,
