@@ -77,6 +77,12 @@ SIGNATURES = {
     "dk_gemm_workspace_bytes": (C.c_size_t, []),
     "dk_conv3x3_bf16": (_i32, [C.POINTER(dk_conv_desc), _vp]),
     "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dk_attention_bias_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i32, _vp]),
+    "dk_embedding_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "dk_layernorm_bf16": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp]),
+    "dk_t5_rmsnorm_bf16": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _vp]),
+    "dk_text_elementwise": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "dk_t5_bias_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "dk_ln_modulate_bf16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dk_qk_norm_rope_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "dk_rope_table_f32": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i32), _i32, _f32, _vp]),

@@ -252,7 +252,8 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");
   // automatic choice (kernel lab, profiles/r01_attention_lab.md): the VALU-lean kernel, 8 waves per
   // workgroup for D = 128 on long sequences (K/V staging shared by 8 waves), 4 waves otherwise
-  const int mode = g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 5 : 4) : g_dk_attn_mode;
+  // a score bias (text encoders) is only implemented by the lean kernel's 4-wave form
+  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 5 : 4) : g_dk_attn_mode;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   int rc = 0;
 #define DK_ATTN_CASE(M, NW, VAR)                                                     \

@@ -39,7 +39,7 @@ __device__ __forceinline__ int k2_swz(int r) { return D == 128 ? (r & 15) : ((r 
 
 typedef __attribute__((address_space(3))) char lds_char;
 
-template <int D, int NW>
+template <int D, int NW, bool HAS_BIAS = false>
 __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) {
   using C = Attn2Cfg<D, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,6 +142,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;  // p = 2^(s*c - m*c)
   const float thr = DK_RESCALE_THR / p.scale;          // threshold on the raw scores
+  const float inv_scale = 1.0f / p.scale;
+  const bf16_t* bias_row = HAS_BIAS ? p.bias + (size_t)head * p.bias_head_stride + (size_t)min(q0 + l31, S - 1) * p.ldb : nullptr;
 
   load_tile(0);
   DK2_STORE_TILE(0)
@@ -167,6 +169,19 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
         const int key = j_ * 64 + (e & 3) + 8 * (e >> 2) + 4 * hi;                                         \
         if (key >= S) s0[e] = -1e30f;                                                                      \
         if (key + 32 >= S) s1[e] = -1e30f;                                                                 \
+      }                                                                                                    \
+    }                                                                                                      \
+    if (HAS_BIAS) { /* scores += bias / scale (the exponent below multiplies by scale * log2 e) */            \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                   \
+        const uint2 b0 = *(const uint2*)(bias_row + j_ * 64 + 8 * g4 + 4 * hi);                             \
+        const uint2 b1 = *(const uint2*)(bias_row + j_ * 64 + 32 + 8 * g4 + 4 * hi);                        \
+        float f0[4], f1[4];                                                                                \
+        unpack2bf(b0.x, f0[0], f0[1]); unpack2bf(b0.y, f0[2], f0[3]);                                      \
+        unpack2bf(b1.x, f1[0], f1[1]); unpack2bf(b1.y, f1[2], f1[3]);                                      \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+          s0[4 * g4 + e] += f0[e] * inv_scale;                                                             \
+          s1[4 * g4 + e] += f1[e] * inv_scale;                                                             \
+        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
     float mloc = fmaxf(s0[0], s1[0]);                                                                      \
@@ -233,21 +248,26 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
   }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool HAS_BIAS = false>
 static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   using C = Attn2Cfg<D, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
-  hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW, HAS_BIAS>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
   return 0;
 }
 
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
   DK_REQUIRE((size_t)p.S * p.ld * 2 < (1ull << 32), "attention2: one batch row of QKV must span < 4 GiB");
+  if (p.bias != nullptr) {  // text encoders: D = 64, short sequences
+    DK_REQUIRE(p.ldb % 64 == 0 && p.ldb >= p.S && ((uintptr_t)p.bias & 7) == 0 && p.bias_head_stride % 4 == 0,
+               "attention bias: row stride must be a multiple of 64 >= S, 8-byte aligned");
+    return p.D == 128 ? launch_attn2<128, 4, true>(p, stream) : launch_attn2<64, 4, true>(p, stream);
+  }
   if (p.D == 128) {
     if (waves == 8) return launch_attn2<128, 8>(p, stream);
     if (waves == 7) return launch_attn2<128, 7>(p, stream);

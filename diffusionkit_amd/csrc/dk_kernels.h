@@ -72,9 +72,22 @@ struct AttnParams {
   int B, H, S, D;
   int ld, ldo;
   float scale;
+  // optional additive score bias (text encoders: CLIP's causal mask clip.py:83-89, T5's relative-position bias
+  // t5.py:61-88): scores = scale * q.k + bias[head * bias_head_stride + q * ldb + k]; ldb a multiple of 64 >= S
+  const bf16_t* bias = nullptr;
+  long bias_head_stride = 0;
+  int ldb = 0;
 };
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
+
+// ---- text-conditioning kernels (text_ops.hip) ---------------------------------------------------
+int dk_launch_embedding(const bf16_t* table, const int* ids, const bf16_t* pos, int pos_rows, bf16_t* out, float* out_f32, int n, int dim,
+                        int vocab, hipStream_t stream);
+int dk_launch_layernorm(const bf16_t* x, bf16_t* out, int M, int h, const bf16_t* w, const bf16_t* b, float eps, hipStream_t stream);
+int dk_launch_t5_rmsnorm(const float* x, bf16_t* out, int M, int h, const bf16_t* w, float eps, hipStream_t stream);
+int dk_launch_text_elementwise(const bf16_t* a, const bf16_t* b, bf16_t* y, float* r, long n, int op, hipStream_t stream);
+int dk_launch_t5_bias(const bf16_t* emb, const int* rel_bucket, int H, int S, int ld, bf16_t* out, hipStream_t stream);
 
 // ---- elementwise / normalisation ---------------------------------------------------------
 // out[m, :] = bf16( LN(x[m, :]) * bf16(1 + scale[b, :]) + shift[b, :] ), b = m / seg_len

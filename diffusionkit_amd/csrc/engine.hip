@@ -83,6 +83,39 @@ extern "C" int dk_attention_bf16(const void* q, const void* k, const void* v, vo
   return dk_launch_attention(p, S_(stream));
 }
 
+extern "C" int dk_attention_bias_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t S, int32_t D,
+                                      int32_t ld, int32_t ldo, float scale, const void* bias, int64_t bias_head_stride, int32_t ldb,
+                                      void* stream) {
+  DK_REQUIRE(bias != nullptr, "bias missing (use dk_attention_bf16 without one)");
+  AttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)out;
+  p.B = B; p.H = H; p.S = S; p.D = D; p.ld = ld; p.ldo = ldo; p.scale = scale;
+  p.bias = (const bf16_t*)bias; p.bias_head_stride = (long)bias_head_stride; p.ldb = ldb;
+  return dk_launch_attention(p, S_(stream));
+}
+extern "C" int dk_embedding_bf16(const void* table, const int32_t* ids, const void* pos, int32_t pos_rows, void* out_bf16, float* out_f32,
+                                 int32_t n, int32_t dim, int32_t vocab, void* stream) {
+  DK_REQUIRE(table && ids && (out_bf16 || out_f32), "null argument");
+  return dk_launch_embedding((const bf16_t*)table, ids, (const bf16_t*)pos, pos_rows, (bf16_t*)out_bf16, out_f32, n, dim, vocab, S_(stream));
+}
+extern "C" int dk_layernorm_bf16(const void* x, void* out, int32_t M, int32_t h, const void* weight, const void* bias, float eps,
+                                 void* stream) {
+  DK_REQUIRE(x && out && weight && M > 0 && h > 0, "bad argument");
+  return dk_launch_layernorm((const bf16_t*)x, (bf16_t*)out, M, h, (const bf16_t*)weight, (const bf16_t*)bias, eps, S_(stream));
+}
+extern "C" int dk_t5_rmsnorm_bf16(const float* x, void* out, int32_t M, int32_t h, const void* weight, float eps, void* stream) {
+  DK_REQUIRE(x && out && weight && M > 0 && h > 0, "bad argument");
+  return dk_launch_t5_rmsnorm(x, (bf16_t*)out, M, h, (const bf16_t*)weight, eps, S_(stream));
+}
+extern "C" int dk_text_elementwise(const void* a, const void* b, void* y, float* r, int64_t n, int32_t op, void* stream) {
+  DK_REQUIRE(a && n > 0 && op >= 0 && op <= 2 && (op == 2 ? r != nullptr : y != nullptr) && (op != 1 || b != nullptr), "bad argument");
+  return dk_launch_text_elementwise((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, r, (long)n, op, S_(stream));
+}
+extern "C" int dk_t5_bias_bf16(const void* emb, const int32_t* rel_bucket, int32_t H, int32_t S, int32_t ld, void* out, void* stream) {
+  DK_REQUIRE(emb && rel_bucket && out && H > 0 && S > 0 && ld >= S && ld % 64 == 0, "bad argument");
+  return dk_launch_t5_bias((const bf16_t*)emb, rel_bucket, H, S, ld, (bf16_t*)out, S_(stream));
+}
+
 extern "C" int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t M, int32_t h, const void* shift,
                                    const void* scale, int32_t mod_stride, int32_t mod_seg_len, int32_t x_seg_len,
                                    int32_t x_seg_stride, float eps, void* stream) {

@@ -102,6 +102,27 @@ int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream);
 int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
                       int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, void* stream);
 
+/* The same with an additive score bias (text encoders): CLIP's causal mask
+ * (clip.py:83-89, one [S, ldb] table for every head: bias_head_stride 0) and T5's relative-position
+ * bias (t5.py:61-88, [H, S, ldb]); scores = scale * q.k + bias.  ldb: multiple of 64, >= S. */
+int dk_attention_bias_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                           int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, const void* bias,
+                           int64_t bias_head_stride, int32_t ldb, void* stream);
+
+/* Text-conditioning helpers (clip.py:28-120, t5.py:60-243):
+ * dk_embedding_bf16: out[i,:] = table[ids[i],:] (+ pos[i % pos_rows,:]); out_bf16 and / or out_f32.
+ * dk_layernorm_bf16: nn.LayerNorm with weight / bias.   dk_t5_rmsnorm_bf16: the T5 RMSNorm over the fp32 stream.
+ * dk_text_elementwise: op 0 y = quick_gelu(a); 1 y = a * b; 2 r_f32 += a.
+ * dk_t5_bias_bf16: out[h,q,k] = emb[rel_bucket[k - q + S - 1], h] (rel_bucket: int32 [2S-1], host-computed). */
+int dk_embedding_bf16(const void* table, const int32_t* ids, const void* pos, int32_t pos_rows, void* out_bf16,
+                      float* out_f32, int32_t n, int32_t dim, int32_t vocab, void* stream);
+int dk_layernorm_bf16(const void* x, void* out, int32_t M, int32_t h, const void* weight, const void* bias,
+                      float eps, void* stream);
+int dk_t5_rmsnorm_bf16(const float* x, void* out, int32_t M, int32_t h, const void* weight, float eps, void* stream);
+int dk_text_elementwise(const void* a, const void* b, void* y, float* r, int64_t n, int32_t op, void* stream);
+int dk_t5_bias_bf16(const void* emb, const int32_t* rel_bucket, int32_t H, int32_t S, int32_t ld, void* out,
+                    void* stream);
+
 /* affine_transform + LayerNorm, mmdit.py:958-972, 838-849.
  * out[m,:] = LN(x[m,:]) * (1 + scale[b,:]) + shift[b,:], b = m / mod_seg_len. */
 int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t M, int32_t h,
