@@ -302,6 +302,79 @@ def vae_encoder_checkpoint_to_reference(sd: StateDict, cfg, prefix: str = "encod
 
 
 # ---------------------------------------------------------------------------------------------
+# text encoders: Hugging Face CLIPTextModel(WithProjection) / T5EncoderModel checkpoints
+# ---------------------------------------------------------------------------------------------
+def clip_checkpoint_to_reference(sd: StateDict, cfg) -> StateDict:
+    """HF ``text_model.*`` CLIP tensors -> reference CLIPTextModel names (behaviour of model_io.py:611-636)."""
+    out: StateDict = {}
+    for k0, t in sd.items():
+        k = k0[len("text_model."):] if k0.startswith("text_model.") else k0
+        if k.endswith("position_ids"):
+            continue  # registered buffer of older transformers versions
+        if k.startswith("embeddings."):
+            k = k[len("embeddings."):]
+        if k.startswith("encoder."):
+            k = k[len("encoder."):]
+        m = re.fullmatch(r"layers\.(\d+)\.(self_attn\.(q|k|v|out)_proj|mlp\.fc([12])|layer_norm([12]))\.(weight|bias)", k)
+        if m:
+            i, leaf = m.group(1), m.group(6)
+            if m.group(3):
+                name = {"q": "query_proj", "k": "key_proj", "v": "value_proj", "out": "out_proj"}[m.group(3)]
+                out[f"layers.{i}.attention.{name}.{leaf}"] = t
+            elif m.group(4):
+                out[f"layers.{i}.linear{m.group(4)}.{leaf}"] = t
+            else:
+                out[f"layers.{i}.layer_norm{m.group(5)}.{leaf}"] = t
+        elif k in ("token_embedding.weight", "position_embedding.weight", "final_layer_norm.weight", "final_layer_norm.bias",
+                   "text_projection.weight"):
+            out[k] = t
+        else:
+            raise CheckpointError(f"unknown CLIP text-encoder key: {k0}")
+    from .text import synth_clip_weights
+    want = synth_clip_weights(cfg, shapes_only=True)
+    _check_against(out, want, "CLIP")
+    return {k: out[k] for k in want}
+
+
+def t5_checkpoint_to_reference(sd: StateDict, cfg) -> StateDict:
+    """HF T5 encoder tensors -> reference SD3T5Encoder names (behaviour of model_io.py:565-608)."""
+    out: StateDict = {}
+    attn = {"q": "query_proj", "k": "key_proj", "v": "value_proj", "o": "out_proj"}
+    for k, t in sd.items():
+        if k in ("shared.weight",) or k.startswith("decoder.") or k.startswith("lm_head."):
+            continue
+        if k == "encoder.embed_tokens.weight":
+            out["wte.weight"] = t
+        elif k == "encoder.final_layer_norm.weight":
+            out["encoder.ln.weight"] = t
+        elif k == "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight":
+            out["encoder.relative_attention_bias.embeddings.weight"] = t
+        elif (m := re.fullmatch(r"encoder\.block\.(\d+)\.layer\.0\.SelfAttention\.(q|k|v|o)\.weight", k)):
+            out[f"encoder.layers.{m.group(1)}.attention.{attn[m.group(2)]}.weight"] = t
+        elif (m := re.fullmatch(r"encoder\.block\.(\d+)\.layer\.(0|1)\.layer_norm\.weight", k)):
+            out[f"encoder.layers.{m.group(1)}.ln{int(m.group(2)) + 1}.weight"] = t
+        elif (m := re.fullmatch(r"encoder\.block\.(\d+)\.layer\.1\.DenseReluDense\.(wi_0|wi_1|wo)\.weight", k)):
+            out[f"encoder.layers.{m.group(1)}.dense.{m.group(2)}.weight"] = t
+        else:
+            raise CheckpointError(f"unknown T5 encoder key: {k}")
+    if "wte.weight" not in out and "shared.weight" in sd:
+        out["wte.weight"] = sd["shared.weight"]
+    from .text import synth_t5_weights
+    want = synth_t5_weights(cfg, shapes_only=True)
+    _check_against(out, want, "T5")
+    return {k: out[k] for k in want}
+
+
+def _check_against(out: StateDict, want, what: str) -> None:
+    missing = sorted(set(want) - set(out))
+    if missing:
+        raise CheckpointError(f"{what} checkpoint lacks {len(missing)} tensors, first: {missing[:3]}")
+    for k, shp in want.items():
+        if tuple(out[k].shape) != shp:
+            raise CheckpointError(f"{k}: shape {tuple(out[k].shape)} != expected {shp}")
+
+
+# ---------------------------------------------------------------------------------------------
 # entry points used by the pipelines (local_ckpt={"mmdit": path_or_dict, "vae_decoder": path_or_dict})
 # ---------------------------------------------------------------------------------------------
 def load_mmdit_checkpoint(src, cfg: MMDiTConfig) -> StateDict:
@@ -331,3 +404,19 @@ def load_vae_encoder_checkpoint(src, cfg) -> StateDict:
         return sd
     pre = "first_stage_model.encoder." if any(k.startswith("first_stage_model.encoder.") for k in sd) else "encoder."
     return vae_encoder_checkpoint_to_reference(sd, cfg, prefix=pre)
+
+
+def load_clip_checkpoint(src, cfg) -> StateDict:
+    """``src``: a .safetensors path or state dict, Hugging Face CLIPTextModel(WithProjection) layout or reference names."""
+    sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if any(k.startswith("layers.") for k in sd):
+        return sd
+    return clip_checkpoint_to_reference(sd, cfg)
+
+
+def load_t5_checkpoint(src, cfg) -> StateDict:
+    sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if "wte.weight" in sd:
+        return sd
+    return t5_checkpoint_to_reference(sd, cfg)
+

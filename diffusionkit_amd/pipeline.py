@@ -152,6 +152,8 @@ class DiffusionPipeline:
             self.load_mmdit()
         if not hasattr(self, "decoder") and self._packed_weights is not None and "vae_decoder" in self._packed_weights:
             self.decoder = VAEDecoderEngine(self.vae_config, self._packed_weights["vae_decoder"])
+        if self._text_encoder is None:
+            self.load_text_encoders()
         if not hasattr(self, "decoder"):
             if isinstance(self.local_ckpt, dict) and "vae_decoder" in self.local_ckpt:
                 from .model_io import load_vae_decoder_checkpoint
@@ -178,9 +180,34 @@ class DiffusionPipeline:
 
     # -- text conditioning (outside the hot path) ------------------------------------------------
     def set_text_encoder(self, fn: Callable) -> None:
-        """Plug in a callable ``fn(text, cfg_weight, negative_text) -> (conditioning, pooled)``
-        (the reference's CLIP/T5 stack, mlx/__init__.py:176-251, is not part of this build)."""
+        """Plug in a callable ``fn(text, cfg_weight, negative_text) -> (conditioning, pooled)``, e.g. a
+        ``diffusionkit_amd.text.TextConditioner`` (the reference's CLIP / T5 stack, mlx/__init__.py:176-251)."""
         self._text_encoder = fn
+
+    def load_text_encoders(self) -> bool:
+        """Builds the CLIP / T5 engines and tokenizers named in ``local_ckpt`` (there is no hub access here, so nothing is
+        downloaded): keys ``clip_l`` / ``clip_g`` / ``t5`` = Hugging Face checkpoint paths (or state dicts),
+        ``tokenizer_l`` / ``tokenizer_g`` = (vocab.json, merges.txt), ``t5_tokenizer`` = a local tokenizer directory
+        (mlx/__init__.py:119-147, model_io.py:788-962).  Returns False (synthetic conditioning stays) when they are absent."""
+        ck = self.local_ckpt if isinstance(self.local_ckpt, dict) else {}
+        need = ("clip_l", "tokenizer_l", "t5", "t5_tokenizer") if self._IS_FLUX else ("clip_l", "tokenizer_l", "clip_g", "tokenizer_g")
+        if not all(k in ck for k in need):
+            return False
+        from . import text as tx
+        from .model_io import load_clip_checkpoint, load_t5_checkpoint
+        clip_l = tx.CLIPTextEngine(tx.CLIP_L, load_clip_checkpoint(ck["clip_l"], tx.CLIP_L), self.device)
+        tok_l = tx.Tokenizer.from_files(*ck["tokenizer_l"], pad_with_eos=True)
+        t5 = t5_tok = clip_g = tok_g = None
+        t5_len = T5_MAX_LENGTH[self.model_version]
+        if "t5" in ck and "t5_tokenizer" in ck and self.use_t5:
+            t5 = tx.T5EncoderEngine(tx.T5_XXL, load_t5_checkpoint(ck["t5"], tx.T5_XXL), self.device)
+            t5_tok = tx.T5Tokenizer(ck["t5_tokenizer"], t5_len)
+        if not self._IS_FLUX:
+            clip_g = tx.CLIPTextEngine(tx.CLIP_G, load_clip_checkpoint(ck["clip_g"], tx.CLIP_G), self.device)
+            tok_g = tx.Tokenizer.from_files(*ck["tokenizer_g"], pad_with_eos=False)
+        self.set_text_encoder(tx.TextConditioner(clip_l, tok_l, t5=t5, t5_tokenizer=t5_tok, clip_g=clip_g, tokenizer_g=tok_g,
+                                                 flux=self._IS_FLUX, t5_max_length=t5_len))
+        return True
 
     def text_len(self) -> int:
         if self._text_len_override is not None:
