@@ -141,3 +141,26 @@ def test_pipeline_with_text_encoders(dev, tmp_path):
     yardstick(p.float(), res["emu"][1], res["fp32"][1], "flux pooled")
     img, log = pipe.generate_image("the cat and the dog", num_steps=2, latent_size=(8, 8), seed=1, verbose=False)
     assert img.size == (64, 64) and log["text_encoding"]["synthetic"] is False
+
+
+def test_sd3_conditioning_assembly(dev, tmp_path):
+    """DiffusionPipeline.encode_text (mlx/__init__.py:197-251): [CLIP-L | CLIP-G | zeros to 4096] tokens followed by the T5
+    tokens (zeros when T5 is off), pooled = [pooled_L | pooled_G]; prompt + negative prompt rows when cfg_weight > 1."""
+    from diffusionkit_amd.text import tokenize_rows
+    from tests.test_text_oracle import _tiny_bpe
+    vp, mp, _ = _tiny_bpe(str(tmp_path))
+    tok_l, tok_g = Tokenizer.from_files(vp, mp, pad_with_eos=True), Tokenizer.from_files(vp, mp, pad_with_eos=False)
+    cl, cg = tiny_clip("quick_gelu", 64), tiny_clip("gelu", 96)
+    wl, wg = synth_clip_weights(cl, seed=31), synth_clip_weights(cg, seed=32)
+    cond = TextConditioner(CLIPTextEngine(cl, wl, dev), tok_l, clip_g=CLIPTextEngine(cg, wg, dev), tokenizer_g=tok_g, flux=False)
+    c, p = cond("the cat", cfg_weight=5.0, negative_text="dog")
+    assert c.shape == (2, 154, 4096) and p.shape == (2, 64 + 96)
+    f = lambda d: {k: v.float() for k, v in d.items()}
+    tl, tg = tokenize_rows(tok_l, "the cat", "dog"), tokenize_rows(tok_g, "the cat", "dog")
+    res = {n: ot.sd3_conditioning(ot.OracleCLIPText(cl, f(wl), P), ot.OracleCLIPText(cg, f(wg), P), None, tl, tg, None)
+           for n, P in (("fp32", Prec()), ("emu", Prec(BF)))}
+    yardstick(c.float(), res["emu"][0], res["fp32"][0], "sd3 conditioning")
+    yardstick(p.float(), res["emu"][1], res["fp32"][1], "sd3 pooled")
+    assert torch.all(c[:, :, 256:] == 0) and torch.all(c[:, 77:] == 0)
+    c1, p1 = cond("the cat", cfg_weight=0.0)  # no negative row without CFG (:203-204)
+    assert c1.shape == (1, 154, 4096) and p1.shape == (1, 160)
