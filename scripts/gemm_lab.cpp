@@ -72,6 +72,10 @@ int main(int argc, char** argv) {
       {4096, 4096, 1024, "K=1024", DK_EPI_BIAS},
       {4096, 4096, 2048, "K=2048", DK_EPI_BIAS},
       {4096, 4096, 16384, "K=16384", DK_EPI_BIAS},
+      {256, 12288, 3072, "flux fc1 txt (M=256)", DK_EPI_BIAS_GELU},
+      {256, 12288, 4096, "t5 qkv (M=256)", DK_EPI_BIAS},
+      {256, 4096, 10240, "t5 wo (M=256)", DK_EPI_BIAS},
+      {1178, 6144, 1536, "sd3 fc1 txt", DK_EPI_BIAS_GELU},
   };
   std::vector<int> modes = {128, 5, 6, 3};
   if (getenv("LAB_MODES")) {  // e.g. LAB_MODES=128,1,11,12 (>= 10: ablation builds, not checked)
