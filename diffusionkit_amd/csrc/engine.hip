@@ -200,6 +200,9 @@ struct Carver {
   }
 };
 
+// workspace handed to every GEMM the engines build (set by dk_mmdit_prepare; one engine per process and device)
+static void* g_linear_ws = nullptr;
+
 static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                                 bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
                                 const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
@@ -213,6 +216,7 @@ static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_s
   p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
   p.gate_seg_len = gate_seg_len > 0 ? gate_seg_len : M; p.gate_stride = gate_stride;
   p.alpha = 1.0f; p.epi = epi;
+  if (g_linear_ws) { p.workspace = g_linear_ws; p.workspace_bytes = dk_streamk_workspace_bytes(); }
   return p;
 }
 
@@ -265,6 +269,7 @@ struct dk_mmdit {
   bool prepared = false, mod_ready = false;
   // workspace views
   bf16_t *X, *XN, *QKV, *ATT, *CAT, *HID, *MOD, *POS;
+  void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_streamk_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
 
@@ -426,6 +431,7 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->vec = (bf16_t*)c.take((size_t)n_t * B * h * 2);
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
+  m->GWS = c.take(dk_streamk_workspace_bytes());
   return c.off;
 }
 
@@ -461,6 +467,9 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
     DK_CHECK_HIP(hipMemcpy2DAsync(m->POS, (size_t)gw * m->h() * 2, m->pos_w + ((size_t)y0 * mh + x0) * m->h(),
                                   (size_t)mh * m->h() * 2, (size_t)gw * m->h() * 2, gh, hipMemcpyDeviceToDevice, st));
   }
+  // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
+  DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_streamk_workspace_bytes() - 4096, 0, 4096, st));
+  g_linear_ws = m->GWS;
   m->prepared = true;
   m->mod_ready = false;
   return 0;
@@ -520,6 +529,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
   DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
   hipStream_t st = S_(stream);
+  g_linear_ws = m->GWS;
   const dk_mmdit_config& c = m->cfg;
   const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F(), r = c.mlp_ratio;
   const int R = m->mod_rows();

@@ -326,7 +326,10 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
       // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial
       // extra wave costs more than the small separate launch)
       const long ta = (long)((a.M + 255) / 256) * (a.N / 256), tb = (long)((b.M + 255) / 256) * (b.N / 256);
-      if ((ta + 255) / 256 == (ta + tb + 255) / 256) return v3 ? dk_launch_gemm256v3(a, &b, stream) : dk_launch_gemm256v2(a, &b, false, stream);
+      // ... unless the v3 kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
+      const bool split_ok = v3 && g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
+      if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok)
+        return v3 ? dk_launch_gemm256v3(a, &b, stream) : dk_launch_gemm256v2(a, &b, false, stream);
     }
   }
   int rc = dk_launch_gemm(a, stream);

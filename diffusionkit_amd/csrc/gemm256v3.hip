@@ -541,11 +541,12 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
   return a_rows * (size_t)p.lda * 2 < (1ull << 32) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
 }
 
-// dk_tune_set("gemm_split", v): 0 never (default), 1 whenever possible, -1 by the cost model below.  Kernel lab
-// (profiles/r01_gemm_lab.md): every workgroup carries ~18 us of fixed cost (launch, first DMA, tail) and a CU runs
-// its K-tiles ~20 % slower when all 256 CUs are busy than when 192 are, so filling the idle CUs of a remainder wave
-// gains at most a few percent on the longest-K shape and loses on the others -- kept as a tested option only.
-int g_dk_v3_split = 0;
+// dk_tune_set("gemm_split", v): -1 (default) split a remainder wave of at most half the CUs into equal pieces when the
+// cost model below says it pays, 0 never, 1 whenever possible.  Kernel lab (profiles/r01_gemm_lab.md): every workgroup
+// carries ~18 us of fixed cost (launch, first DMA, tail) and a CU runs its K-tiles ~20 % slower when all 256 CUs are busy
+// than when 192 are, so a remainder of MORE than half the CUs (finisher + several producer pieces in turn on the
+// spare CUs) loses on every shape but the longest-K one and is only taken when forced.
+int g_dk_v3_split = -1;
 
 // How the tiles beyond the last full wave of the CUs are cut along K (see SplitArgs).  n_rem == 0: no split.
 struct SplitPlan {
@@ -560,6 +561,7 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
   const int E = G - T;
   int S, ks, t_steps;  // t_steps: K-tile steps until the split wave is done
   if (T > G / 2) {  // one producer piece per tile, c = ceil(T / E) of them in turn on each of the E spare CUs
+    if (g_dk_v3_split < 0) return none;
     S = 2;
     const int c = (T + E - 1) / E;
     ks = (nk * c + c) / (c + 1);  // ~ nk * c / (c + 1), rounded up: the finishers must not end before the producers
@@ -572,7 +574,7 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
   }
   if (S < 2 || ks < 1 || nk - ks < S - 1 || T * (S - 1) > 256) return none;
   // a K-tile step costs about 1.45 us; splitting costs a slab write + read and a flag round trip per tile
-  if (g_dk_v3_split < 0 && (nk - t_steps) * 1.45 < 14.0) return none;
+  if (g_dk_v3_split < 0 && (nk - t_steps) * 1.45 < 25.0) return none;
   return SplitPlan{tiles - T, T, S, ks};
 }
 

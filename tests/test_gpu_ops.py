@@ -243,7 +243,7 @@ def test_gemm_v3_remainder_split(dev, M, N, K, epi):
         y0 = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
     finally:
         ops.tune("gemm", -1)
-        ops.tune("gemm_split", 0)
+        ops.tune("gemm_split", -1)
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
     assert max_abs(y0.float(), y.float()) <= 0.02 * float(ref.abs().max()) + 1e-2  # a bf16 ulp where the summation order differs
     assert float((y0.float() != y.float()).float().mean()) < 0.02
