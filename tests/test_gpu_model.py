@@ -375,3 +375,26 @@ def test_vae_full_size_split_invariance(dev):
     assert torch.equal(u1, u2)
     assert psnr(img0.cpu(), img1.cpu()) > 45.0
     assert float((u0 != u1).float().mean()) < 0.05
+
+
+def test_flux_full_size_properties(dev):
+    """BASELINE configs[1] at full size (FLUX.1-schnell, latent 128x128, 256 text tokens; 2 Euler steps to keep it short)
+    through size-independent properties: same seed -> bit-identical latents, another seed -> a different image, finite
+    values, and independence of the GEMM remainder split beyond fp32 summation order."""
+    from diffusionkit_amd import ops
+    from diffusionkit_amd.pipeline import FluxPipeline
+    pipe = FluxPipeline(w16=True, a16=True, device=dev)  # seeded synthetic weights of the production architecture
+    cfg = pipe.mmdit_config
+    cond = randn(1, 256, cfg.token_level_text_embed_dim, seed=71).to(dev, BF)
+    pooled = randn(1, cfg.pooled_text_embed_dim, seed=72).to(dev, BF)
+    run = lambda seed: pipe.denoise_latents(cond, pooled, num_steps=2, cfg_weight=0.0, latent_size=(128, 128), seed=seed)[0]
+    a, b, c = run(0), run(0), run(1)
+    assert a.shape == (1, 128, 128, 16) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)
+    try:
+        ops.tune("gemm_split", 0)
+        d = run(0)
+    finally:
+        ops.tune("gemm_split", -1)
+    assert psnr(d.cpu(), a.cpu()) > 40.0
