@@ -43,7 +43,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// nn.GELU() (exact erf form, mmdit.py:421): gelu(x) = x * Phi(x) with erfc(|x| / sqrt 2) from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 rounding that follows) -- 14 VALU instructions instead of ocml erff's 34; written
+// on erfc so that the negative tail has no cancellation: gelu = 0.5 x erfc(-x / sqrt 2).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // erfc(|x| / sqrt 2)
+  const float h = 0.5f * x * erfc_z;
+  return x >= 0.f ? x - h : h;
+}
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
