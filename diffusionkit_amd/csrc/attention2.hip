@@ -95,14 +95,19 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
     st_kl[i] = kl;
     g_off[i] = (unsigned)kl * row_bytes + (unsigned)c8 * 16u;
     ks_off[i] = (unsigned)(kl * C::ROWB + ((c8 ^ k2_swz<D>(kl)) << 4));
-    // V image: [d/16][key][16]; odd d-blocks store key rows with bit 2 flipped (tr-read bank halves)
-    vs_off[i] = (unsigned)((c8 >> 1) * 2048 + (kl ^ (((c8 >> 1) & 1) << 2)) * 32 + (c8 & 1) * 16);
+    // V image: [d/16][key][16]; d-block b stores key row kl at row kl ^ f(b), f(b) = ((b & 1) << 2) | (b & 3): bit 2 puts the
+    // two blocks a tr-read touches on different bank halves, bits 0-1 spread the four blocks one staging store writes
+    // (same key, 2 KiB apart = the same banks) over the four 32-byte rows of a 128-byte bank period (it was a 4-way conflict)
+    vs_off[i] = (unsigned)((c8 >> 1) * 2048 + (kl ^ ((((c8 >> 1) & 1) << 2) | ((c8 >> 1) & 3))) * 32 + (c8 & 1) * 16);
   }
   unsigned kr_off[D / 16];  // K fragment read: row l31 (+32 per sub-tile as an immediate), swizzled chunk
 #pragma unroll
   for (int kk = 0; kk < D / 16; ++kk) kr_off[kk] = (unsigned)(l31 * C::ROWB + (((kk * 2 + hi) ^ k2_swz<D>(l31)) << 4));
   const int x16 = (lane >> 4) & 1, p16 = lane & 15;
-  const unsigned vr_off = (unsigned)(x16 * 2048 + (4 * (hi ^ x16) + (p16 >> 2)) * 32 + (p16 & 3) * 8);
+  unsigned vr_off[2];  // by parity of the 32-wide d-tile dt: the lane reads block b = 2*dt + x16, f(b) & 3 = 2*(dt & 1) + x16
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    vr_off[par] = (unsigned)(x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8);
 
   u32x4 kreg[C::NCH], vreg[C::NCH];
   const int ntiles = (S + 63) / 64;
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
         _Pragma("unroll") for (int e = 0; e < 8; ++e) pf[e] = (__bf16)(u == 0 ? s0[8 * tt + e] : s1[8 * tt + e]); \
         _Pragma("unroll") for (int dt = 0; dt < D / 32; ++dt) {                                            \
           const int imm = V_OFF + (BUF) * C::TILE_BYTES + dt * 4096 + (32 * u + 16 * tt) * 32;             \
-          const s16x4 vh0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + vr_off)); \
-          const s16x4 vh1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + 256 + vr_off)); \
+          const s16x4 vh0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + vr_off[dt & 1])); \
+          const s16x4 vh1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm + 256 + vr_off[dt & 1])); \
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7)); \
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);                         \
         }                                                                                                  \
