@@ -244,65 +244,81 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       __builtin_amdgcn_sched_barrier(0);                                                                          \
     }                                                                                                             \
   } while (0)
-#define DK_LOOP(PH)                                                                                            \
-  for (int i = 0; i < nk; ++i) {                                                                               \
-    constexpr bool in_loop = true;                                                                             \
-    const unsigned bo = (i & 1) * KT_BYTES;                                                                    \
-    const bool on1 = i >= 1 && i + 1 < nk; /* second half of tile i+1 (first half went out in S3 of i-1) */     \
-    DK_RDA_HI(1, bo, 0);                                                                                       \
-    DK_WAIT8(4, wf0, xf0);                                                                                     \
-    DK_MMG(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1);                                                                   \
-    DK_RDW(1, bo, 1);                                                                                          \
-    DK_RDA_LO(0, bo, 1);                                                                                       \
-    DK_WAIT4(8, xf1);                                                                                          \
-    DK_MMG(0, 1, 4, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, on1);                                                                     \
-    DK_RDA_HI(1, bo, 1);                                                                                       \
-    DK_WAIT8(4, wf1, xf0);                                                                                     \
-    DK_MMG(1, 0, 0, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, on1);                                                                     \
+// One K-tile for the wave group that reads its fragments in FRONT of every 16-MFMA step.  ON1 / ON2 (compile-time):
+// whether the DMA pieces of K-tile i+1 (second part) / i+2 (first part) are issued -- false only in the last two
+// K-tiles, so that the steady-state loop carries no branches around the pieces.
+#define DK_ITER(PH, ON1, ON2)                                                                                    \
+  {                                                                                                              \
+    constexpr bool in_loop = true;                                                                               \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
+    DK_RDA_HI(1, bo, 0);                                                                                         \
+    DK_WAIT8(4, wf0, xf0);                                                                                       \
+    DK_MMG(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1);                                                         \
+    DK_RDW(1, bo, 1);                                                                                            \
+    DK_RDA_LO(0, bo, 1);                                                                                         \
+    DK_WAIT4(8, xf1);                                                                                            \
+    DK_MMG(0, 1, 4, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, ON1);                                              \
+    DK_RDA_HI(1, bo, 1);                                                                                         \
+    DK_WAIT8(4, wf1, xf0);                                                                                       \
+    DK_MMG(1, 0, 0, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, ON1);                                   \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
-    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                        \
-    asm volatile("" ::: "memory");                                                                             \
-    DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */      \
-    DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */      \
-    DK_MMG(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk);                                                              \
+    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
+    asm volatile("" ::: "memory");                                                                               \
+    DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */        \
+    DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */        \
+    DK_MMG(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2);                                                                \
   }
-
-// Skewed form (DK_V3_SKEW, default): the same K-tile for the second wave of each SIMD with its fragment reads in the
-// MIDDLE of every 16-MFMA step instead of in front of it, so that the two waves of a SIMD do not run their
-// read / wait sections at the same time (+1.5-2 % in the lab).
-#define DK_LOOP_SKEW(PH, R)                                                                                    \
-  for (int i = 0; i < nk; ++i) {                                                                               \
-    constexpr bool in_loop = true;                                                                             \
-    const unsigned bo = (i & 1) * KT_BYTES;                                                                    \
-    const bool on1 = i >= 1 && i + 1 < nk;                                                                     \
-    DK_WAIT8(0, wf0, xf0);                                                                                     \
-    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1, 0, R);                                                \
-    DK_RDA_HI(1, bo, 0);                                                                                       \
-    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, on1, R, 16);                                               \
-    DK_WAIT4(0, xf1);                                                                                          \
-    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, 0, R);                                                             \
-    DK_RDW(1, bo, 1);                                                                                          \
-    DK_RDA_LO(0, bo, 1);                                                                                       \
-    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, R, 16);                                                            \
-    DK_WAIT8(0, wf1, xf0);                                                                                     \
-    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, 0, R);                                                             \
-    DK_RDA_HI(1, bo, 1);                                                                                       \
-    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, R, 16);                                                            \
+// The same K-tile for the second wave of each SIMD with its fragment reads behind MFMA slot R of every step instead of
+// in front of it, so that the two waves of a SIMD do not run their read / wait sections at the same time (+1.5-2 %).
+#define DK_ITER_SKEW(PH, R, ON1, ON2)                                                                            \
+  {                                                                                                              \
+    constexpr bool in_loop = true;                                                                               \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
+    DK_WAIT8(0, wf0, xf0);                                                                                       \
+    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, 0, R);                                                  \
+    DK_RDA_HI(1, bo, 0);                                                                                         \
+    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, R, 16);                                                 \
+    DK_WAIT4(0, xf1);                                                                                            \
+    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, 0, R);                                                               \
+    DK_RDW(1, bo, 1);                                                                                            \
+    DK_RDA_LO(0, bo, 1);                                                                                         \
+    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, R, 16);                                                              \
+    DK_WAIT8(0, wf1, xf0);                                                                                       \
+    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, 0, R);                                                               \
+    DK_RDA_HI(1, bo, 1);                                                                                         \
+    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, R, 16);                                                              \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
-    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                        \
-    asm volatile("" ::: "memory");                                                                             \
-    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk, 0, R);                                                \
-    DK_RDW(0, bo ^ KT_BYTES, 0);                                                                               \
-    DK_RDA_LO(0, bo ^ KT_BYTES, 0);                                                                            \
-    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, i + 2 < nk, R, 16);                                               \
+    if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
+    asm volatile("" ::: "memory");                                                                               \
+    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2, 0, R);                                                         \
+    DK_RDW(0, bo ^ KT_BYTES, 0);                                                                                 \
+    DK_RDA_LO(0, bo ^ KT_BYTES, 0);                                                                              \
+    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2, R, 16);                                                        \
+  }
+// all K-tiles of this workgroup: branch-free steady state, then the two tiles that issue less.  The fragments in flight
+// at a section boundary are waited for there (an inline-asm load must not be in flight across a compiler-visible merge).
+#define DK_DRIVE(ITER, ...)                                                                                      \
+  {                                                                                                              \
+    int i = 0;                                                                                                   \
+    for (; i + 2 < nk; ++i) ITER(__VA_ARGS__, true, true)                                                        \
+    DK_WAIT8(0, wf0, xf0);                                                                                       \
+    if (i + 1 < nk) {                                                                                            \
+      ITER(__VA_ARGS__, true, false)                                                                             \
+      ++i;                                                                                                       \
+      DK_WAIT8(0, wf0, xf0);                                                                                     \
+    }                                                                                                            \
+    ITER(__VA_ARGS__, false, false)                                                                              \
+    DK_WAIT8(0, wf0, xf0);                                                                                       \
   }
 
   {
     bf16x8 wf0[4], wf1[4], xf0[4], xf1[4];
+    // prologue: K-tile 0 completely, and the first part of K-tile 1 (the steady state issues the rest in its first step)
     issue_tile(0);
     if (nk > 1) {
-      issue_tile(1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+      for (int gidx = 0; gidx < DK_V3_N3; ++gidx) issue_piece(1, gidx);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DK_V3_N3) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -314,31 +330,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     if (wm == 0) {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
-#if DK_V3_SKEW == 2
-      if (wn & 1) {
-        DK_LOOP_SKEW(DK_V3_PH0, 4)
-      } else {
-        DK_LOOP(DK_V3_PH0)
-      }
-#else
-      DK_LOOP(DK_V3_PH0)
-#endif
-      DK_WAIT8(0, wf0, xf0);
+      DK_DRIVE(DK_ITER, DK_V3_PH0)
     } else {
       DK_RDW(0, 0u, 0);
       DK_RDA_LO(0, 0u, 0);
-#if DK_V3_SKEW == 2  /* lab: four read positions, by SIMD parity as well */
-      if (wn & 1) {
-        DK_LOOP_SKEW(DK_V3_PH1, 12)
-      } else {
-        DK_LOOP_SKEW(DK_V3_PH1, 8)
-      }
-#elif DK_V3_SKEW
-      DK_LOOP_SKEW(DK_V3_PH1, DK_V3_SKEW_R)
+#if DK_V3_SKEW
+      DK_DRIVE(DK_ITER_SKEW, DK_V3_PH1, DK_V3_SKEW_R)
 #else
-      DK_LOOP(DK_V3_PH1)
+      DK_DRIVE(DK_ITER, DK_V3_PH1)
 #endif
-      DK_WAIT8(0, wf0, xf0);
     }
   }
 #undef DK_LDS_RD
@@ -349,8 +349,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_WAIT8
 #undef DK_MMG
 #undef DK_MMGR
-#undef DK_LOOP
-#undef DK_LOOP_SKEW
+#undef DK_ITER
+#undef DK_ITER_SKEW
+#undef DK_DRIVE
 
   // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
   // All waves passed the last loop barrier after their final ds_read, so the ring is free.
