@@ -99,6 +99,13 @@ int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, 
                            const bf16_t* qw, const bf16_t* kw, float eps, const float* rope,
                            int row_seg_len, int row_seg_stride, int pos_off, int S_pos,
                            hipStream_t stream);
+// two row sets (image / text stream of a double block) per launch
+int dk_launch_ln_modulate2(const bf16_t* x0, bf16_t* out0, int M0, const bf16_t* shift0, const bf16_t* scale0, int seg0, const bf16_t* x1,
+                           bf16_t* out1, int M1, const bf16_t* shift1, const bf16_t* scale1, int seg1, int ldx, int ldo, int h,
+                           int mod_stride, int x_seg_stride, float eps, hipStream_t stream);
+int dk_launch_qk_norm_rope2(bf16_t* qkv0, int rows0, const bf16_t* qw0, const bf16_t* kw0, int seg0, int pos0, bf16_t* qkv1, int rows1,
+                            const bf16_t* qw1, const bf16_t* kw1, int seg1, int pos1, int ld, int q_off, int k_off, int H, int D,
+                            float eps, const float* rope, int row_seg_stride, hipStream_t stream);
 int dk_launch_silu(const bf16_t* x, bf16_t* y, long n, hipStream_t stream);
 int dk_launch_add(const bf16_t* a, const bf16_t* b, int b_rows, bf16_t* y, int rows, int cols, hipStream_t stream);
 int dk_launch_timestep_embedding(const float* t, int n, int rep, int dim, float max_period, int embed_dtype,

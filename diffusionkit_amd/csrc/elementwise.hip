@@ -9,13 +9,26 @@
 // mx.fast.layer_norm(x, 1 + scale, shift, eps)); LayerNorm :838-849 (no affine, eps 1e-6).
 // One wave per row, row kept in registers (two-pass variance), 4 rows per workgroup.
 // ---------------------------------------------------------------------------------------------
+// One launch serves up to two jobs (the image and the text stream of a double block, mmdit.py:568-675: the text
+// stream's 256 rows would otherwise run alone on the chip): blocks [0, blocks_a) belong to job a, the rest to job b.
+struct LnJob {
+  const bf16_t* x;
+  bf16_t* out;
+  const bf16_t *shift, *scale;
+  int ldx, ldo, M, mod_stride, seg_len, x_seg_len, x_seg_stride;
+};
 template <int NCH>
-__global__ __launch_bounds__(256) void dk_ln_modulate_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ out,
-                                                             int ldo, int M, int h, const bf16_t* __restrict__ shift,
-                                                             const bf16_t* __restrict__ scale, int mod_stride, int seg_len,
-                                                             int x_seg_len, int x_seg_stride, float eps) {
+__global__ __launch_bounds__(256) void dk_ln_modulate_kernel(LnJob ja, LnJob jb, int blocks_a, int h, float eps) {
+  const bool first = (int)blockIdx.x < blocks_a;
+  const LnJob& j = first ? ja : jb;
+  const bf16_t* __restrict__ x = j.x;
+  bf16_t* __restrict__ out = j.out;
+  const bf16_t* __restrict__ shift = j.shift;
+  const bf16_t* __restrict__ scale = j.scale;
+  const int ldx = j.ldx, ldo = j.ldo, M = j.M, mod_stride = j.mod_stride, seg_len = j.seg_len, x_seg_len = j.x_seg_len,
+            x_seg_stride = j.x_seg_stride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = blockIdx.x * 4 + wave;
+  const int m = ((int)blockIdx.x - (first ? 0 : blocks_a)) * 4 + wave;
   if (m >= M) return;
   const size_t xrow = (size_t)((m / x_seg_len) * x_seg_stride + (m % x_seg_len)) * ldx;
   const int b = m / seg_len;
@@ -74,17 +87,16 @@ __global__ __launch_bounds__(256) void dk_ln_modulate_kernel(const bf16_t* __res
   }
 }
 
-int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M, int h, const bf16_t* shift,
-                          const bf16_t* scale, int mod_stride, int seg_len, int x_seg_len, int x_seg_stride, float eps,
-                          hipStream_t stream) {
+static int launch_ln_jobs(const LnJob& a, const LnJob& b, int h, float eps, hipStream_t stream) {
   DK_REQUIRE(h % 8 == 0 && h <= 4096, "hidden size must be a multiple of 8 and <= 4096");
-  DK_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && mod_stride % 8 == 0, "strides must keep 16-byte alignment");
-  dim3 grid((M + 3) / 4), block(256);
+  for (const LnJob* j : {&a, &b})
+    DK_REQUIRE(j->M == 0 || (j->ldx % 8 == 0 && j->ldo % 8 == 0 && j->mod_stride % 8 == 0), "strides must keep 16-byte alignment");
+  const int blocks_a = (a.M + 3) / 4, blocks_b = (b.M + 3) / 4;
+  dim3 grid(blocks_a + blocks_b), block(256);
   const int nch = (h / 8 + 63) / 64;
 #define LN_CASE(N)                                                                                         \
   case N:                                                                                                  \
-    hipLaunchKernelGGL(dk_ln_modulate_kernel<N>, grid, block, 0, stream, x, ldx, out, ldo, M, h, shift, scale, \
-                       mod_stride, seg_len, x_seg_len, x_seg_stride, eps);                                 \
+    hipLaunchKernelGGL(dk_ln_modulate_kernel<N>, grid, block, 0, stream, a, b, blocks_a, h, eps);          \
     break;
   switch (nch) {
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
@@ -94,6 +106,26 @@ int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M,
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+static LnJob ln_job(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M, const bf16_t* shift, const bf16_t* scale, int mod_stride,
+                    int seg_len, int x_seg_len, int x_seg_stride) {
+  LnJob j;
+  j.x = x; j.out = out; j.shift = shift; j.scale = scale; j.ldx = ldx; j.ldo = ldo; j.M = M; j.mod_stride = mod_stride;
+  j.seg_len = seg_len; j.x_seg_len = x_seg_len; j.x_seg_stride = x_seg_stride;
+  return j;
+}
+int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M, int h, const bf16_t* shift,
+                          const bf16_t* scale, int mod_stride, int seg_len, int x_seg_len, int x_seg_stride, float eps,
+                          hipStream_t stream) {
+  LnJob none = ln_job(nullptr, 8, nullptr, 8, 0, nullptr, nullptr, 8, 1, 1, 0);
+  return launch_ln_jobs(ln_job(x, ldx, out, ldo, M, shift, scale, mod_stride, seg_len, x_seg_len, x_seg_stride), none, h, eps, stream);
+}
+// two row sets (image / text stream) of the same hidden size in one launch
+int dk_launch_ln_modulate2(const bf16_t* x0, bf16_t* out0, int M0, const bf16_t* shift0, const bf16_t* scale0, int seg0, const bf16_t* x1,
+                           bf16_t* out1, int M1, const bf16_t* shift1, const bf16_t* scale1, int seg1, int ldx, int ldo, int h,
+                           int mod_stride, int x_seg_stride, float eps, hipStream_t stream) {
+  return launch_ln_jobs(ln_job(x0, ldx, out0, ldo, M0, shift0, scale0, mod_stride, seg0, seg0, x_seg_stride),
+                        ln_job(x1, ldx, out1, ldo, M1, shift1, scale1, mod_stride, seg1, seg1, x_seg_stride), h, eps, stream);
+}
 
 // ---------------------------------------------------------------------------------------------
 // In-place per-head RMSNorm (learned weight) followed by RoPE on the q and k column groups of a
@@ -102,15 +134,24 @@ int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M,
 // D/8 lanes cooperate on one (row, head, q|k) item; rope == nullptr skips the rotation,
 // qw == nullptr skips the norm.
 // ---------------------------------------------------------------------------------------------
+struct QkJob {  // (two jobs per launch like LnJob)
+  bf16_t* qkv;
+  const bf16_t *qw, *kw;
+  int rows, row_seg_len, row_seg_stride, pos_off;
+};
 template <int D>
-__global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(bf16_t* __restrict__ qkv, int ld, int q_off, int k_off, int rows,
-                                                              int H, const bf16_t* __restrict__ qw, const bf16_t* __restrict__ kw,
-                                                              float eps, const float* __restrict__ rope, int row_seg_len,
-                                                              int row_seg_stride, int pos_off) {
+__global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(QkJob ja, QkJob jb, int blocks_a, int ld, int q_off, int k_off, int H, float eps,
+                                                              const float* __restrict__ rope) {
+  const bool first = (int)blockIdx.x < blocks_a;
+  const QkJob& jj = first ? ja : jb;
+  bf16_t* __restrict__ qkv = jj.qkv;
+  const bf16_t* __restrict__ qw = jj.qw;
+  const bf16_t* __restrict__ kw = jj.kw;
+  const int rows = jj.rows, row_seg_len = jj.row_seg_len, row_seg_stride = jj.row_seg_stride, pos_off = jj.pos_off;
   constexpr int LPI = D / 8;  // lanes per item
   // 32-bit index arithmetic (rows * 2H * LPI < 2^31, checked by the launcher): 64-bit divisions cost more VALU
   // work than the 16 bytes this lane moves
-  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned gid = (blockIdx.x - (first ? 0u : (unsigned)blocks_a)) * 256u + threadIdx.x;
   const unsigned item = gid / LPI;
   const int sub = (int)(gid % LPI);
   const unsigned nitems = (unsigned)rows * 2u * (unsigned)H;
@@ -160,24 +201,36 @@ __global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(bf16_t* __restrict
   }
 }
 
+static int launch_qk_jobs(const QkJob& a, const QkJob& b, int ld, int q_off, int k_off, int H, int D, float eps, const float* rope,
+                          hipStream_t stream) {
+  DK_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+  DK_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0, "alignment");
+  const long ta = (long)a.rows * 2 * H * (D / 8), tb = (long)b.rows * 2 * H * (D / 8);
+  DK_REQUIRE(ta + tb < (1L << 31) - 512, "qk_norm_rope: rows * 2H * D/8 must stay below 2^31");
+  const int blocks_a = (int)((ta + 255) / 256), blocks_b = (int)((tb + 255) / 256);
+  dim3 grid(blocks_a + blocks_b), block(256);
+  if (D == 128)
+    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<128>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope);
+  else
+    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<64>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, int H, int D, const bf16_t* qw,
                            const bf16_t* kw, float eps, const float* rope, int row_seg_len, int row_seg_stride, int pos_off,
                            int S_pos, hipStream_t stream) {
   (void)S_pos;
-  DK_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
-  DK_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0, "alignment");
   if (qw == nullptr && rope == nullptr) return 0;
-  const long threads = (long)rows * 2 * H * (D / 8);
-  DK_REQUIRE(threads < (1L << 31) - 256, "qk_norm_rope: rows * 2H * D/8 must stay below 2^31");
-  dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-  if (D == 128)
-    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<128>, grid, block, 0, stream, qkv, ld, q_off, k_off, rows, H, qw, kw, eps, rope,
-                       row_seg_len, row_seg_stride, pos_off);
-  else
-    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<64>, grid, block, 0, stream, qkv, ld, q_off, k_off, rows, H, qw, kw, eps, rope,
-                       row_seg_len, row_seg_stride, pos_off);
-  DK_CHECK_HIP(hipGetLastError());
-  return 0;
+  QkJob a{qkv, qw, kw, rows, row_seg_len, row_seg_stride, pos_off}, none{nullptr, nullptr, nullptr, 0, 1, 0, 0};
+  return launch_qk_jobs(a, none, ld, q_off, k_off, H, D, eps, rope, stream);
+}
+// the two streams of a double block (same buffer geometry, own weights / row segments / positions) in one launch
+int dk_launch_qk_norm_rope2(bf16_t* qkv0, int rows0, const bf16_t* qw0, const bf16_t* kw0, int seg0, int pos0, bf16_t* qkv1, int rows1,
+                            const bf16_t* qw1, const bf16_t* kw1, int seg1, int pos1, int ld, int q_off, int k_off, int H, int D,
+                            float eps, const float* rope, int row_seg_stride, hipStream_t stream) {
+  if (qw0 == nullptr && rope == nullptr) return 0;
+  QkJob a{qkv0, qw0, kw0, rows0, seg0, row_seg_stride, pos0}, b{qkv1, qw1, kw1, rows1, seg1, row_seg_stride, pos1};
+  return launch_qk_jobs(a, b, ld, q_off, k_off, H, D, eps, rope, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -561,18 +561,17 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
     const StreamW& wt = m->dtxt[i];
     const bool txt_post = !m->txt_skipped(i);
     // pre_sdpa (mmdit.py:440-519): LN-modulate, q/k/v projection, QK-norm (+ RoPE)
-    DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img, mod_img + h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
-    DK_TRY(dk_launch_ln_modulate(X_txt, h, XN_txt, h, Mt, h, mod_txt, mod_txt + h, mod_stride, S_t, S_t, S, c.layer_norm_eps, st));
+    // (image and text stream of each elementwise stage in ONE launch: the 256 text rows do not run alone on the chip)
+    DK_TRY(dk_launch_ln_modulate2(X_img, XN_img, Mi, mod_img, mod_img + h, S_i, X_txt, XN_txt, Mt, mod_txt, mod_txt + h, S_t, h, h, h,
+                                  mod_stride, S, c.layer_norm_eps, st));
     DK_TRY(dk_launch_gemm_pair(
         linear_params(XN_img, h, Mi, 0, wi.qkv_w, wi.qkv_b, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S, Mi, 3 * h, h, DK_EPI_BIAS, nullptr,
                       0, 0, nullptr, 0, 0, 0),
         linear_params(XN_txt, h, Mt, 0, wt.qkv_w, wt.qkv_b, m->QKV, 3 * h, S_t, S, Mt, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0,
                       0, 0),
         st));
-    DK_TRY(dk_launch_qk_norm_rope(m->QKV + (size_t)S_t * 3 * h, 3 * h, 0, h, Mi, c.num_heads, m->D(), wi.qn, wi.kn, 1e-6f,
-                                  c.use_rope ? m->rope : nullptr, S_i, S, S_t, S, st));
-    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, Mt, c.num_heads, m->D(), wt.qn, wt.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
-                                  S_t, S, 0, S, st));
+    DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
+                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
@@ -589,14 +588,16 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
       DK_TRY(dk_launch_gemm(o_img, st));
     }
     // residual += gate_mlp * fc2(gelu(fc1(LN-mod(residual))))
-    DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img + 3 * h, mod_img + 4 * h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
+    if (txt_post)
+      DK_TRY(dk_launch_ln_modulate2(X_img, XN_img, Mi, mod_img + 3 * h, mod_img + 4 * h, S_i, X_txt, XN_txt, Mt, mod_txt + 3 * h,
+                                    mod_txt + 4 * h, S_t, h, h, h, mod_stride, S, c.layer_norm_eps, st));
+    else
+      DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img + 3 * h, mod_img + 4 * h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
     const GemmParams fc1_img = linear_params(XN_img, h, Mi, 0, wi.fc1_w, wi.fc1_b, HID_img, r * h, Mi, 0, Mi, r * h, h, DK_EPI_BIAS_GELU,
                                              nullptr, 0, 0, nullptr, 0, 0, 0);
     const GemmParams fc2_img = linear_params(HID_img, r * h, Mi, 0, wi.fc2_w, wi.fc2_b, X_img, h, S_i, S, Mi, h, r * h, DK_EPI_GATE_RES,
                                              mod_img + 5 * h, S_i, mod_stride, X_img, h, S_i, S);
     if (txt_post) {
-      DK_TRY(dk_launch_ln_modulate(X_txt, h, XN_txt, h, Mt, h, mod_txt + 3 * h, mod_txt + 4 * h, mod_stride, S_t, S_t, S, c.layer_norm_eps,
-                                   st));
       DK_TRY(dk_launch_gemm_pair(fc1_img,
                                  linear_params(XN_txt, h, Mt, 0, wt.fc1_w, wt.fc1_b, HID_txt, r * h, Mt, 0, Mt, r * h, h,
                                                DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr, 0, 0, 0),
