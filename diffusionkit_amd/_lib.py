@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdk_hip.so")
+# DK_HIP_LIB: another build of the same library, for same-box A/B measurements (scripts/ab_lib.sh); the in-tree one otherwise
+LIB_PATH = os.environ.get("DK_HIP_LIB") or os.path.join(_HERE, "libdk_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dk_hip.h")
 
 
