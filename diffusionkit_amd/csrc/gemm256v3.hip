@@ -16,9 +16,15 @@
 // 8 A fragments (ds_read_b128 each: row = base + (lane & 15), 16-byte chunk = 4 * kk + (lane >> 4)) for
 // 32 MFMAs.  A K-tile is 4 steps of 16 MFMAs:  (kk0, m 0-63), (kk0, m 64-127), (kk1, m 0-63), (kk1, m 64-127),
 // with two W register sets and two A register sets reloaded one step ahead (inline-asm ds_read_b128,
-// hand-counted s_waitcnt lgkmcnt), the tile barrier between steps 2 and 3, and the 8 global_load_lds
-// instructions of a K-tile spread over steps 3 and 0, one in front of every fourth MFMA, on opposite slots for
-// the two wave groups of a SIMD.
+// hand-counted s_waitcnt lgkmcnt), the tile barrier between steps 2 and 3, and the 8 LDS-DMA instructions
+// (buffer_load_dwordx4 ... lds: SGPR resource + 32-bit lane offset) of a K-tile spread over steps 3 and 0, one in
+// front of every fourth MFMA, on opposite slots for the two wave groups of a SIMD.  The second wave of each SIMD issues
+// its fragment reads in the middle of a step instead of in front of it (DK_ITER_SKEW), and the steady state carries no
+// branches: the last two K-tiles, which issue less DMA, are peeled (DK_DRIVE).
+//
+// Tail: accumulators -> wave-private LDS image (fp32, XOR-swizzled) -> row-major read-back, 8 columns per lane, one
+// 16-byte store per lane and row; bias / GELU (erfc polynomial) / SiLU / gate * x + residual on the way.
+// Remainder waves can be cut along K (SplitArgs, plan_split): finisher + producer pieces through fp32 slabs.
 //
 // C / D layout of the swapped-operand MFMA (A-operand = W fragment, B-operand = activation fragment):
 // lane holds output row m = mf*16 + (lane & 15), columns n = nf*16 + 4*(lane >> 4) + {0..3}.
@@ -28,7 +34,8 @@
 #include "dk_kernels.h"
 
 #ifndef DK_V3_ABL
-#define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n): 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile barrier
+#define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n), bit mask: 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile
+                     // barrier, 8 producers do not store, 16 finishers neither wait nor read, 32 no C stores, 64 no tail (run-time false)
 #endif
 
 // placement of the 4 DMA pieces inside a 16-MFMA step: in front of MFMA slots PH, PH + STR, ... (PH0 / PH1 for the
