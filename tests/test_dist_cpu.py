@@ -38,6 +38,9 @@ def _worker(rank, world, port, q):
     got = dk.broadcast_weights(packed, "cpu", src=0)
     ref = pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=99), "cpu")
     ok = set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+    # the chunked form the full-size blob takes (several collectives, a ragged last chunk)
+    got = dk.broadcast_weights(packed, "cpu", src=0, chunk_elems=100_003)
+    ok = ok and set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
     imgs = torch.full((2, 4, 4, 3), r, dtype=torch.uint8)
     g = dk.gather_images(imgs, dst=0)
     if r == 0:
