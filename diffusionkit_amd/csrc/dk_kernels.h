@@ -128,7 +128,7 @@ int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, flo
 int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,
                               const bf16_t* gamma, const bf16_t* beta, int do_silu, hipStream_t stream);
 int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t stream);
-int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream);
+int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream, int ldy = 0);  // ldy > R: zero-padded rows
 int dk_launch_pad_channels(const float* x, bf16_t* y, long npix, int C, int Cpad, hipStream_t stream);
 int dk_launch_image_post(const bf16_t* x, int ldx, float* img, unsigned char* u8, long npix, hipStream_t stream);
 int dk_launch_latent_sample(const bf16_t* mom, int ldm, const float* noise, float* out, long npix, int L, hipStream_t stream);

@@ -711,8 +711,8 @@ static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
   v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
-  v->Vt = (bf16_t*)c.take(tok * Cm * 2);
-  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 8) * 2);
+  v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
+  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
   v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
   return c.off;
 }
@@ -768,7 +768,8 @@ struct VaeRun {
   int attention(const bf16_t* x, bf16_t* out, int H, int Wd, int C, const std::string& p) {
     const long HW = (long)H * Wd;
     const int T = (int)HW;
-    DK_REQUIRE(T % 8 == 0 && T <= 16384, "VAE attention supports up to 16384 tokens (multiple of 8)");
+    DK_REQUIRE(T % 4 == 0 && T <= 16384, "VAE attention supports up to 16384 tokens (even latent sides)");
+    const int Tp = (int)align_up((size_t)T, 64);  // K of the P.V product: zero-padded probability columns / V^T rows
     DK_TRY(gn(x, v->T1, HW, C, p + ".group_norm", 0));
     const bf16_t *qw = W(p + ".query_proj.weight"), *qb = W(p + ".query_proj.bias");
     const bf16_t *kw = W(p + ".key_proj.weight"), *kb = W(p + ".key_proj.bias");
@@ -783,15 +784,14 @@ struct VaeRun {
       GemmParams g;
       memset(&g, 0, sizeof(g));
       g.A = v->Qb + (size_t)b * T * C; g.W = v->Kb + (size_t)b * T * C; g.C = v->SCORES;
-      g.M = T; g.N = T; g.K = C; g.lda = C; g.ldc = T;
+      g.M = T; g.N = T; g.K = C; g.lda = C; g.ldc = Tp;
       g.a_seg_len = g.c_seg_len = g.r_seg_len = g.gate_seg_len = T;
       g.alpha = scale; g.epi = DK_EPI_BIAS;
       DK_TRY(dk_launch_gemm(g, st));
-      DK_TRY(dk_launch_softmax_rows(v->SCORES, T, T, T, st));
-      DK_TRY(dk_launch_transpose(v->Vb + (size_t)b * T * C, v->Vt, T, C, st));
-      // attn @ V: A = probs [T,T], W = V^T [C,T]; result into Y rows of this batch
-      DK_REQUIRE(T % 64 == 0, "VAE attention token count must be a multiple of 64");
-      DK_TRY(linear_plain(v->SCORES, v->Vt, nullptr, v->Y + (size_t)b * T * C, T, C, T, DK_EPI_BIAS, st));
+      DK_TRY(dk_launch_softmax_rows(v->SCORES, T, T, Tp, st));  // columns [T, Tp) come out as zeros
+      DK_TRY(dk_launch_transpose(v->Vb + (size_t)b * T * C, v->Vt, T, C, st, Tp));
+      // attn @ V: A = probs [T, Tp], W = V^T [C, Tp]; result into Y rows of this batch
+      DK_TRY(linear_plain(v->SCORES, v->Vt, nullptr, v->Y + (size_t)b * T * C, T, C, Tp, DK_EPI_BIAS, st));
     }
     // out_proj + residual
     return linear_call(v->Y, C, B * T, 0, ow, ob, out, C, B * T, 0, B * T, C, C, DK_EPI_RES, nullptr, 0, 0, x, C, B * T, 0, st);
@@ -871,8 +871,8 @@ static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
   v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
-  v->Vt = (bf16_t*)c.take(tok * Cm * 2);
-  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 8) * 2);
+  v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
+  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
   v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
   return c.off;
 }

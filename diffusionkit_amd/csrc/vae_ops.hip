@@ -161,13 +161,14 @@ int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C,
 
 // ---------------------------------------------------------------------------------------------
 // In-place row softmax on a bf16 matrix (fp32 math), one workgroup per row, row cached in
-// registers (cols <= 16384).  reference: mx.softmax(scores) in vae.py:51.
+// registers (ld <= 16384).  Columns [cols, ld) -- the padding up to the K-tile multiple the P.V GEMM needs -- are
+// ignored on input (they may hold anything) and written as zeros.  reference: mx.softmax(scores) in vae.py:51.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict__ x, int cols, int ld) {
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   bf16_t* row = x + (size_t)blockIdx.x * ld;
-  const int nchunks = cols >> 3;
+  const int nchunks = ld >> 3;
   float v[8][8];
   float mx = -3.0e38f;
 #pragma unroll
@@ -176,9 +177,11 @@ __global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict
     if (c < nchunks) {
       const u32x4 raw = *(const u32x4*)(row + c * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unpack2bf(raw[e], v[i][2 * e], v[i][2 * e + 1]);
-        mx = fmaxf(mx, fmaxf(v[i][2 * e], v[i][2 * e + 1]));
+      for (int e = 0; e < 4; ++e) unpack2bf(raw[e], v[i][2 * e], v[i][2 * e + 1]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (c * 8 + e >= cols) v[i][e] = -3.0e38f;  // padding: by index, not by value
+        mx = fmaxf(mx, v[i][e]);
       }
     }
   }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict
     if (c < nchunks) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[i][e] = __expf(v[i][e] - mx);
+        v[i][e] = c * 8 + e < cols ? __expf(v[i][e] - mx) : 0.f;
         sum += v[i][e];
       }
     }
@@ -214,29 +217,31 @@ __global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict
   }
 }
 int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t stream) {
-  DK_REQUIRE(cols % 8 == 0 && cols <= 16384 && ld % 8 == 0, "softmax row length must be a multiple of 8 and <= 16384");
+  DK_REQUIRE(cols >= 1 && cols <= ld && ld <= 16384 && ld % 8 == 0, "softmax: 1 <= cols <= ld <= 16384, ld a multiple of 8");
   hipLaunchKernelGGL(dk_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, cols, ld);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-// y[c, r] = x[r, c]
-__global__ void dk_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int R, int Cc) {
+// y[c, r] = x[r, c] for r < R, zero for R <= r < ldy (row stride of y)
+__global__ void dk_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int R, int Cc, int ldy) {
   __shared__ bf16_t tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
   for (int j = ty; j < 32; j += 8) {
     const int r = by + j, c = bx + tx;
-    if (r < R && c < Cc) tile[j][tx] = x[(size_t)r * Cc + c];
+    if (c < Cc) tile[j][tx] = r < R ? x[(size_t)r * Cc + c] : (bf16_t)0;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;
-    if (r < R && c < Cc) y[(size_t)c * R + r] = tile[tx][j];
+    if (r < ldy && c < Cc) y[(size_t)c * ldy + r] = tile[tx][j];
   }
 }
-int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream) {
-  hipLaunchKernelGGL(dk_transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, x, y, R, Cc);
+int dk_launch_transpose(const bf16_t* x, bf16_t* y, int R, int Cc, hipStream_t stream, int ldy) {
+  if (ldy <= 0) ldy = R;
+  DK_REQUIRE(ldy >= R, "transpose: output row stride must cover the rows");
+  hipLaunchKernelGGL(dk_transpose_kernel, dim3((Cc + 31) / 32, (ldy + 31) / 32), dim3(256), 0, stream, x, y, R, Cc, ldy);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -175,8 +175,11 @@ def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, s
 
 
 def softmax_rows_(x: Tensor) -> Tensor:
+    """In-place row softmax; ``x`` may be a column slice ``buf[:, :cols]`` of a wider row-major buffer, whose remaining
+    columns are then written as zeros (row stride a multiple of 8)."""
     lib = _lib.load()
-    _require_cuda(x, "x", BF)
+    if not (x.is_cuda and x.dtype == BF and x.dim() == 2 and x.stride(1) == 1):
+        raise _lib.DkHipError("softmax_rows_: bf16 GPU matrix with unit column stride expected")
     _lib.check(lib.dk_softmax_rows_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), _stream()), "dk_softmax_rows_bf16")
     return x
 

@@ -172,7 +172,7 @@ def test_cfg_denoiser_call_matches_step(dev):
         den.step_index(123.0)  # unknown timestep: the reference raises KeyError on its dict
 
 
-@pytest.mark.parametrize("vcfg,hw", [(tiny_vae(), (8, 8)), (tiny_vae(), (16, 8))])
+@pytest.mark.parametrize("vcfg,hw", [(tiny_vae(), (8, 8)), (tiny_vae(), (16, 8)), (tiny_vae(), (6, 10)), (tiny_vae(), (8, 12))])
 def test_vae_decode_tiny(dev, vcfg, hw):
     from diffusionkit_amd.engine import VAEDecoderEngine
     named = synth_vae_weights(vcfg, seed=4321)
@@ -398,3 +398,20 @@ def test_flux_full_size_properties(dev):
     finally:
         ops.tune("gemm_split", -1)
     assert psnr(d.cpu(), a.cpu()) > 40.0
+
+
+def test_sd3_pipeline_text_lengths_and_cfg(dev):
+    """SD3 public surface with its two conditioning lengths (mlx/__init__.py:197-251): 77 CLIP tokens + 512 T5 tokens, or
+    154 when T5 is off (zeros of the CLIP length, :241-244); CFG on (prompt + negative row) and off."""
+    from diffusionkit_amd.pipeline import DiffusionPipeline
+    cfg = tiny_sd3()
+    for use_t5, n in ((True, 77 + 512), (False, 154)):
+        pipe = DiffusionPipeline(w16=True, a16=True, shift=3.0, use_t5=use_t5, mmdit_config=cfg, vae_config=tiny_vae(), device=dev)
+        assert pipe.text_len() == n
+        c, p = pipe.encode_text("a photo", cfg_weight=5.0, negative_text="blurry")
+        assert c.shape == (2, n, cfg.token_level_text_embed_dim) and p.shape == (2, cfg.pooled_text_embed_dim)
+        img, log = pipe.generate_image("a photo", num_steps=2, cfg_weight=5.0, negative_text="blurry", latent_size=(8, 12), seed=5,
+                                       verbose=False)
+        assert img.size == (96, 64) and len(log["denoising"]["iter_time"]) == 2
+        img0, _ = pipe.generate_image("a photo", num_steps=2, cfg_weight=0.0, latent_size=(8, 12), seed=5, verbose=False)
+        assert img0.size == (96, 64) and np.asarray(img0).tobytes() != np.asarray(img).tobytes()  # guidance changes the image

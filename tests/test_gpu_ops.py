@@ -409,6 +409,14 @@ def test_softmax_and_transpose(dev):
     assert rel_l2(torch.softmax(x, -1), y.float()) < TOL_SINGLE_OP
     z = ops.transpose(g(x, dev))
     assert torch.equal(z.float().cpu(), x.t())
+    # ragged row length inside a padded row (the VAE attention's score matrix for an odd token count): the padding is
+    # ignored on input (NaNs there must not leak) and comes out as zeros
+    buf = g(x, dev).clone()
+    buf[:, 100:] = float("nan")
+    y = ops.softmax_rows_(buf[:, :100])
+    full = buf.float().cpu()
+    assert rel_l2(torch.softmax(x[:, :100], -1), full[:, :100]) < TOL_SINGLE_OP
+    assert torch.all(full[:, 100:] == 0)
 
 
 @pytest.mark.parametrize("flux,cfg_on", [(True, False), (False, True), (True, True)])
