@@ -216,9 +216,32 @@ __global__ __launch_bounds__(256) void dk_softmax_rows_kernel(bf16_t* __restrict
     }
   }
 }
+// the same for rows that do not fit the register cache (more than 16384 columns: latents beyond 128 x 128): three passes
+// over the row through L2
+__global__ __launch_bounds__(256) void dk_softmax_long_rows_kernel(bf16_t* __restrict__ x, int cols, int ld) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16_t* row = x + (size_t)blockIdx.x * ld;
+  float mx = -3.0e38f;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, bf2f(row[c]));
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += __expf(bf2f(row[c]) - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid; c < ld; c += 256) row[c] = c < cols ? f2bf(__expf(bf2f(row[c]) - mx) * inv) : (bf16_t)0;
+}
 int dk_launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, hipStream_t stream) {
-  DK_REQUIRE(cols >= 1 && cols <= ld && ld <= 16384 && ld % 8 == 0, "softmax: 1 <= cols <= ld <= 16384, ld a multiple of 8");
-  hipLaunchKernelGGL(dk_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, cols, ld);
+  DK_REQUIRE(cols >= 1 && cols <= ld && ld % 8 == 0, "softmax: 1 <= cols <= ld, ld a multiple of 8");
+  if (ld > 16384)
+    hipLaunchKernelGGL(dk_softmax_long_rows_kernel, dim3(rows), dim3(256), 0, stream, x, cols, ld);
+  else
+    hipLaunchKernelGGL(dk_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, cols, ld);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -417,6 +417,12 @@ def test_softmax_and_transpose(dev):
     full = buf.float().cpu()
     assert rel_l2(torch.softmax(x[:, :100], -1), full[:, :100]) < TOL_SINGLE_OP
     assert torch.all(full[:, 100:] == 0)
+    # rows longer than the register cache (latents beyond 128 x 128)
+    xl = randn(3, 16384 + 4096, seed=71, scale=3.0)
+    bl = g(xl, dev).clone()
+    ops.softmax_rows_(bl[:, :20000])
+    fl = bl.float().cpu()
+    assert rel_l2(torch.softmax(bf16r(xl)[:, :20000], -1), fl[:, :20000]) < TOL_SINGLE_OP and torch.all(fl[:, 20000:] == 0)
 
 
 @pytest.mark.parametrize("flux,cfg_on", [(True, False), (False, True), (True, True)])
