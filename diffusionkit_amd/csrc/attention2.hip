@@ -39,7 +39,7 @@ __device__ __forceinline__ int k2_swz(int r) { return D == 128 ? (r & 15) : ((r 
 
 typedef __attribute__((address_space(3))) char lds_char;
 
-template <int D, int NW, bool HAS_BIAS = false>
+template <int D, int NW, bool HAS_BIAS = false, bool QFUSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) {
   using C = Attn2Cfg<D, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,6 +78,49 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
     const bf16_t* qp = Qb + (size_t)qrow * p.ld + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+    if (QFUSE) {
+      // QKNorm + RoPE of this lane's query row on the fly (same fp32 arithmetic and bf16 rounding points as
+      // dk_qk_norm_rope_kernel): the lane and its partner (lane ^ 32) hold the two halves of every 16-element group
+      float v[D / 16][8];
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[kk][e] = (float)qf[kk][e];
+      if (p.qn_a != nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[kk][e] * v[kk][e];
+        ss += __shfl_xor(ss, 32, 64);
+        const float r = rsqrtf(ss / (float)D + p.qn_eps);
+        const bf16_t* w = (qrow < p.qn_split ? p.qn_a : p.qn_b) + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) {
+          const bf16x8 wv = *(const bf16x8*)(w + kk * 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[kk][e] = round_bf16(v[kk][e] * r * (float)wv[e]);
+        }
+      }
+      if (p.q_rope != nullptr) {
+        const float* tab = p.q_rope + ((size_t)qrow * (D / 2) + hi * 4) * 2;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) {
+          const f32x4 t0 = *(const f32x4*)(tab + kk * 16), t1 = *(const f32x4*)(tab + kk * 16 + 4);
+          const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float c = cs[2 * i], sn = cs[2 * i + 1], xe = v[kk][2 * i], xo = v[kk][2 * i + 1];
+            v[kk][2 * i] = c * xe - sn * xo;
+            v[kk][2 * i + 1] = sn * xe + c * xo;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)v[kk][e];
+    }
   }
 
   // ---- per-thread constants: staging chunk coordinates, global lane offsets, LDS offsets ----
@@ -253,16 +296,17 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
   }
 }
 
-template <int D, int NW, bool HAS_BIAS = false>
+template <int D, int NW, bool HAS_BIAS = false, bool QFUSE = false>
 static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   using C = Attn2Cfg<D, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW, HAS_BIAS, QFUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     C::LDS_BYTES));
     attr_set = true;
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
-  hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW, HAS_BIAS>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW, HAS_BIAS, QFUSE>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
   return 0;
 }
 
@@ -272,6 +316,11 @@ int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
     DK_REQUIRE(p.ldb % 64 == 0 && p.ldb >= p.S && ((uintptr_t)p.bias & 7) == 0 && p.bias_head_stride % 4 == 0,
                "attention bias: row stride must be a multiple of 64 >= S, 8-byte aligned");
     return p.D == 128 ? launch_attn2<128, 4, true>(p, stream) : launch_attn2<64, 4, true>(p, stream);
+  }
+  if (p.qn_a != nullptr || p.q_rope != nullptr) {  // query-side QKNorm / RoPE fused into the Q load (MMDiT call sites)
+    DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
+    if (p.D == 128) return waves == 8 ? launch_attn2<128, 8, false, true>(p, stream) : launch_attn2<128, 4, false, true>(p, stream);
+    return waves == 8 ? launch_attn2<64, 8, false, true>(p, stream) : launch_attn2<64, 4, false, true>(p, stream);
   }
   if (p.D == 128) {
     if (waves == 8) return launch_attn2<128, 8>(p, stream);

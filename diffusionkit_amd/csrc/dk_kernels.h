@@ -77,6 +77,14 @@ struct AttnParams {
   const bf16_t* bias = nullptr;
   long bias_head_stride = 0;
   int ldb = 0;
+  // optional QKNorm (mmdit.py:754-764) + RoPE (:934-942) of the QUERY rows inside the kernel's Q load (the keys keep their
+  // own pass, dk_launch_qk_norm_rope*(..., k_only)): rows s < qn_split use weight qn_a, the others qn_b; q_rope = the
+  // [S, D/2, 2] cos/sin table indexed by s, or null
+  const bf16_t* qn_a = nullptr;
+  const bf16_t* qn_b = nullptr;
+  int qn_split = 0;
+  float qn_eps = 1e-6f;
+  const float* q_rope = nullptr;
 };
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
@@ -98,14 +106,14 @@ int dk_launch_ln_modulate(const bf16_t* x, int ldx, bf16_t* out, int ldo, int M,
 int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, int H, int D,
                            const bf16_t* qw, const bf16_t* kw, float eps, const float* rope,
                            int row_seg_len, int row_seg_stride, int pos_off, int S_pos,
-                           hipStream_t stream);
+                           hipStream_t stream, int k_only = 0);
 // two row sets (image / text stream of a double block) per launch
 int dk_launch_ln_modulate2(const bf16_t* x0, bf16_t* out0, int M0, const bf16_t* shift0, const bf16_t* scale0, int seg0, const bf16_t* x1,
                            bf16_t* out1, int M1, const bf16_t* shift1, const bf16_t* scale1, int seg1, int ldx, int ldo, int h,
                            int mod_stride, int x_seg_stride, float eps, hipStream_t stream);
 int dk_launch_qk_norm_rope2(bf16_t* qkv0, int rows0, const bf16_t* qw0, const bf16_t* kw0, int seg0, int pos0, bf16_t* qkv1, int rows1,
                             const bf16_t* qw1, const bf16_t* kw1, int seg1, int pos1, int ld, int q_off, int k_off, int H, int D,
-                            float eps, const float* rope, int row_seg_stride, hipStream_t stream);
+                            float eps, const float* rope, int row_seg_stride, hipStream_t stream, int k_only = 0);
 int dk_launch_silu(const bf16_t* x, bf16_t* y, long n, hipStream_t stream);
 int dk_launch_add(const bf16_t* a, const bf16_t* b, int b_rows, bf16_t* y, int rows, int cols, hipStream_t stream);
 int dk_launch_timestep_embedding(const float* t, int n, int rep, int dim, float max_period, int embed_dtype,

@@ -141,7 +141,7 @@ struct QkJob {  // (two jobs per launch like LnJob)
 };
 template <int D>
 __global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(QkJob ja, QkJob jb, int blocks_a, int ld, int q_off, int k_off, int H, float eps,
-                                                              const float* __restrict__ rope) {
+                                                              const float* __restrict__ rope, int k_only) {
   const bool first = (int)blockIdx.x < blocks_a;
   const QkJob& jj = first ? ja : jb;
   bf16_t* __restrict__ qkv = jj.qkv;
@@ -154,12 +154,14 @@ __global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(QkJob ja, QkJob jb
   const unsigned gid = (blockIdx.x - (first ? 0u : (unsigned)blocks_a)) * 256u + threadIdx.x;
   const unsigned item = gid / LPI;
   const int sub = (int)(gid % LPI);
-  const unsigned nitems = (unsigned)rows * 2u * (unsigned)H;
+  // k_only: the queries are normalised / rotated inside the attention kernel's Q load, this pass touches the keys
+  const unsigned per_row = (k_only ? 1u : 2u) * (unsigned)H;
+  const unsigned nitems = (unsigned)rows * per_row;
   const bool active = item < nitems;
   const unsigned it = active ? item : nitems - 1;
-  const int m = (int)(it / (2u * (unsigned)H));
-  const int rem = (int)(it - (unsigned)m * 2u * (unsigned)H);
-  const int which = rem >= H ? 1 : 0, head = rem - which * H;
+  const int m = (int)(it / per_row);
+  const int rem = (int)(it - (unsigned)m * per_row);
+  const int which = k_only ? 1 : (rem >= H ? 1 : 0), head = k_only ? rem : rem - which * H;
   const int seg = m / row_seg_len, pos_in = m % row_seg_len;
   bf16_t* ptr = qkv + (size_t)(seg * row_seg_stride + pos_in) * ld + (which ? k_off : q_off) + head * D + sub * 8;
   const u32x4 raw = *(const u32x4*)ptr;
@@ -202,35 +204,36 @@ __global__ __launch_bounds__(256) void dk_qk_norm_rope_kernel(QkJob ja, QkJob jb
 }
 
 static int launch_qk_jobs(const QkJob& a, const QkJob& b, int ld, int q_off, int k_off, int H, int D, float eps, const float* rope,
-                          hipStream_t stream) {
+                          hipStream_t stream, int k_only = 0) {
   DK_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
   DK_REQUIRE(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0, "alignment");
-  const long ta = (long)a.rows * 2 * H * (D / 8), tb = (long)b.rows * 2 * H * (D / 8);
+  const int per_row = (k_only ? 1 : 2) * H;
+  const long ta = (long)a.rows * per_row * (D / 8), tb = (long)b.rows * per_row * (D / 8);
   DK_REQUIRE(ta + tb < (1L << 31) - 512, "qk_norm_rope: rows * 2H * D/8 must stay below 2^31");
   const int blocks_a = (int)((ta + 255) / 256), blocks_b = (int)((tb + 255) / 256);
   dim3 grid(blocks_a + blocks_b), block(256);
   if (D == 128)
-    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<128>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope);
+    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<128>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope, k_only);
   else
-    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<64>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope);
+    hipLaunchKernelGGL(dk_qk_norm_rope_kernel<64>, grid, block, 0, stream, a, b, blocks_a, ld, q_off, k_off, H, eps, rope, k_only);
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int dk_launch_qk_norm_rope(bf16_t* qkv, int ld, int q_off, int k_off, int rows, int H, int D, const bf16_t* qw,
                            const bf16_t* kw, float eps, const float* rope, int row_seg_len, int row_seg_stride, int pos_off,
-                           int S_pos, hipStream_t stream) {
+                           int S_pos, hipStream_t stream, int k_only) {
   (void)S_pos;
   if (qw == nullptr && rope == nullptr) return 0;
   QkJob a{qkv, qw, kw, rows, row_seg_len, row_seg_stride, pos_off}, none{nullptr, nullptr, nullptr, 0, 1, 0, 0};
-  return launch_qk_jobs(a, none, ld, q_off, k_off, H, D, eps, rope, stream);
+  return launch_qk_jobs(a, none, ld, q_off, k_off, H, D, eps, rope, stream, k_only);
 }
 // the two streams of a double block (same buffer geometry, own weights / row segments / positions) in one launch
 int dk_launch_qk_norm_rope2(bf16_t* qkv0, int rows0, const bf16_t* qw0, const bf16_t* kw0, int seg0, int pos0, bf16_t* qkv1, int rows1,
                             const bf16_t* qw1, const bf16_t* kw1, int seg1, int pos1, int ld, int q_off, int k_off, int H, int D,
-                            float eps, const float* rope, int row_seg_stride, hipStream_t stream) {
+                            float eps, const float* rope, int row_seg_stride, hipStream_t stream, int k_only) {
   if (qw0 == nullptr && rope == nullptr) return 0;
   QkJob a{qkv0, qw0, kw0, rows0, seg0, row_seg_stride, pos0}, b{qkv1, qw1, kw1, rows1, seg1, row_seg_stride, pos1};
-  return launch_qk_jobs(a, b, ld, q_off, k_off, H, D, eps, rope, stream);
+  return launch_qk_jobs(a, b, ld, q_off, k_off, H, D, eps, rope, stream, k_only);
 }
 
 // ---------------------------------------------------------------------------------------------

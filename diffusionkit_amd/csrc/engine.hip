@@ -19,10 +19,12 @@ extern "C" int dk_abi_version(void) { return DK_ABI_VERSION; }
 extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
 
 int g_dk_attn_mode = -1;
+int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the queries inside the attention kernel's Q load (1, default) or as a separate pass (0)
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
+  if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "gemm_sched") == 0) { g_dk_v2_sched = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
@@ -199,6 +201,9 @@ struct Carver {
     return p;
   }
 };
+
+// the lean attention kernel (modes -1, 4, 5, 6) can normalise / rotate the queries in its Q load; the first-generation one cannot
+static int fuse_q() { return g_dk_fuse_q && (g_dk_attn_mode < 0 || g_dk_attn_mode >= 4) ? 1 : 0; }
 
 // workspace handed to every GEMM the engines build (set by dk_mmdit_prepare; one engine per process and device)
 static void* g_linear_ws = nullptr;
@@ -570,11 +575,13 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
         linear_params(XN_txt, h, Mt, 0, wt.qkv_w, wt.qkv_b, m->QKV, 3 * h, S_t, S, Mt, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0,
                       0, 0),
         st));
+    // QKNorm + RoPE: the keys in one pass over the buffer, the queries inside the attention kernel's Q load
     DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
-                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st));
+                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
+    if (fuse_q()) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // post_sdpa, sequential form (mmdit.py:537-548): residual += gate_attn * o_proj(attn)
     const GemmParams o_img = linear_params(m->ATT + (size_t)S_t * h, h, S_i, S, wi.o_w, wi.o_b, X_img, h, S_i, S, Mi, h, h, DK_EPI_GATE_RES,
@@ -625,10 +632,11 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
       DK_TRY(dk_launch_gemm(l1, st));
     }
     DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
-                                  S, S, 0, S, st));
+                                  S, S, 0, S, st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->CAT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = ldcat; ap.scale = scale;
+    if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
     DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, ldcat, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
