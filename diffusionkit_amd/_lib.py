@@ -116,6 +116,7 @@ SIGNATURES = {
     "dk_profile_enable": (_i32, [_i32]),
     "dk_profile_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dk_tune_set": (_i32, [C.c_char_p, _i32]),
+    "dk_weight_pitch": (_i32, [_i32]),
 }
 
 _lib: Optional[C.CDLL] = None

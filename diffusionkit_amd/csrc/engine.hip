@@ -20,6 +20,11 @@ extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
 
 int g_dk_attn_mode = -1;
 int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the queries inside the attention kernel's Q load (1, default) or as a separate pass (0)
+// Rows of K >= g_dk_pitch_min_k elements (the [h, 5h] linear2 and [h, 4h] fc2 weights of FLUX and the activations they
+// multiply) are stored with 64 elements of padding: a 24-30 KB row stride makes the K-tile DMA of 256 rows camp on a few
+// memory channels (linear2 of FLUX: 369 -> 345 us with the padded pitch, profiles/r01_gemm_lab_pitch.log).
+int g_dk_pitch_min_k = 8192;
+extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
@@ -27,6 +32,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "gemm_sched") == 0) { g_dk_v2_sched = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
+  if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }
@@ -211,11 +217,11 @@ static void* g_linear_ws = nullptr;
 static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                                 bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
                                 const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
-                                int r_seg_stride) {
+                                int r_seg_stride, int ldw = 0) {
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.gate = gate; p.res = res;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldw = ldw;
   p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride;
   p.c_seg_len = c_seg_len; p.c_seg_stride = c_seg_stride;
   p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
@@ -228,11 +234,11 @@ static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_s
 static int linear_call(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                        bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
                        const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
-                       int r_seg_stride, hipStream_t st) {
+                       int r_seg_stride, hipStream_t st, int ldw = 0) {
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.gate = gate; p.res = res;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldw = ldw;
   p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride;
   p.c_seg_len = c_seg_len; p.c_seg_stride = c_seg_stride;
   p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
@@ -274,6 +280,7 @@ struct dk_mmdit {
   bool prepared = false, mod_ready = false;
   // workspace views
   bf16_t *X, *XN, *QKV, *ATT, *CAT, *HID, *MOD, *POS;
+  int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_streamk_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
@@ -422,8 +429,10 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->XN = (bf16_t*)c.take(BS * h * 2);
   m->QKV = (bf16_t*)c.take(BS * 3 * h * 2);
   m->ATT = (bf16_t*)c.take(BS * h * 2);
-  const size_t hid = BS * m->cfg.mlp_ratio * h * 2;  // MLP hidden of both streams of a double block (image rows first)
-  const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)(1 + m->cfg.mlp_ratio) * h * 2 : 0;
+  m->ldh = dk_weight_pitch(m->cfg.mlp_ratio * h);
+  m->ldcat = dk_weight_pitch((1 + m->cfg.mlp_ratio) * h);
+  const size_t hid = BS * m->ldh * 2;  // MLP hidden of both streams of a double block (image rows first)
+  const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)m->ldcat * 2 : 0;
   m->CAT = (bf16_t*)c.take(cat > hid ? cat : hid);  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
   m->HID = m->CAT;
   m->MOD = (bf16_t*)c.take((size_t)n_t * B * m->mod_rows() * h * 2);
@@ -522,10 +531,10 @@ static int post_sdpa_seq(dk_mmdit* m, const StreamW& w, int row_off, int S_s, co
                      S_s, mod_stride, Xs, h, S_s, S, st));
   // residual += gate_mlp * fc2(gelu(fc1(LN-mod(residual))))
   DK_TRY(dk_launch_ln_modulate(Xs, h, m->XN, h, M, h, mod + 3 * h, mod + 4 * h, mod_stride, S_s, S_s, S, m->cfg.layer_norm_eps, st));
-  DK_TRY(linear_call(m->XN, h, M, 0, w.fc1_w, w.fc1_b, m->HID, r * h, M, 0, M, r * h, h, DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr,
+  DK_TRY(linear_call(m->XN, h, M, 0, w.fc1_w, w.fc1_b, m->HID, m->ldh, M, 0, M, r * h, h, DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr,
                      0, 0, 0, st));
-  DK_TRY(linear_call(m->HID, r * h, M, 0, w.fc2_w, w.fc2_b, Xs, h, S_s, S, M, h, r * h, DK_EPI_GATE_RES, mod + 5 * h, S_s,
-                     mod_stride, Xs, h, S_s, S, st));
+  DK_TRY(linear_call(m->HID, m->ldh, M, 0, w.fc2_w, w.fc2_b, Xs, h, S_s, S, M, h, r * h, DK_EPI_GATE_RES, mod + 5 * h, S_s,
+                     mod_stride, Xs, h, S_s, S, st, m->ldh));
   return 0;
 }
 
@@ -555,7 +564,8 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   bf16_t* XN_img = m->XN;
   bf16_t* XN_txt = m->XN + (size_t)B * S_i * h;
   bf16_t* HID_img = m->HID;
-  bf16_t* HID_txt = m->HID + (size_t)B * S_i * r * h;
+  const int ldh = m->ldh;
+  bf16_t* HID_txt = m->HID + (size_t)B * S_i * ldh;
   bf16_t* X_img = m->X + (size_t)S_t * h;
   bf16_t* X_txt = m->X;
   const int Mi = B * S_i, Mt = B * S_t;
@@ -600,18 +610,18 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
                                     mod_txt + 4 * h, S_t, h, h, h, mod_stride, S, c.layer_norm_eps, st));
     else
       DK_TRY(dk_launch_ln_modulate(X_img, h, XN_img, h, Mi, h, mod_img + 3 * h, mod_img + 4 * h, mod_stride, S_i, S_i, S, c.layer_norm_eps, st));
-    const GemmParams fc1_img = linear_params(XN_img, h, Mi, 0, wi.fc1_w, wi.fc1_b, HID_img, r * h, Mi, 0, Mi, r * h, h, DK_EPI_BIAS_GELU,
+    const GemmParams fc1_img = linear_params(XN_img, h, Mi, 0, wi.fc1_w, wi.fc1_b, HID_img, ldh, Mi, 0, Mi, r * h, h, DK_EPI_BIAS_GELU,
                                              nullptr, 0, 0, nullptr, 0, 0, 0);
-    const GemmParams fc2_img = linear_params(HID_img, r * h, Mi, 0, wi.fc2_w, wi.fc2_b, X_img, h, S_i, S, Mi, h, r * h, DK_EPI_GATE_RES,
-                                             mod_img + 5 * h, S_i, mod_stride, X_img, h, S_i, S);
+    const GemmParams fc2_img = linear_params(HID_img, ldh, Mi, 0, wi.fc2_w, wi.fc2_b, X_img, h, S_i, S, Mi, h, r * h, DK_EPI_GATE_RES,
+                                             mod_img + 5 * h, S_i, mod_stride, X_img, h, S_i, S, ldh);
     if (txt_post) {
       DK_TRY(dk_launch_gemm_pair(fc1_img,
-                                 linear_params(XN_txt, h, Mt, 0, wt.fc1_w, wt.fc1_b, HID_txt, r * h, Mt, 0, Mt, r * h, h,
+                                 linear_params(XN_txt, h, Mt, 0, wt.fc1_w, wt.fc1_b, HID_txt, ldh, Mt, 0, Mt, r * h, h,
                                                DK_EPI_BIAS_GELU, nullptr, 0, 0, nullptr, 0, 0, 0),
                                  st));
       DK_TRY(dk_launch_gemm_pair(fc2_img,
-                                 linear_params(HID_txt, r * h, Mt, 0, wt.fc2_w, wt.fc2_b, X_txt, h, S_t, S, Mt, h, r * h, DK_EPI_GATE_RES,
-                                               mod_txt + 5 * h, S_t, mod_stride, X_txt, h, S_t, S),
+                                 linear_params(HID_txt, ldh, Mt, 0, wt.fc2_w, wt.fc2_b, X_txt, h, S_t, S, Mt, h, r * h, DK_EPI_GATE_RES,
+                                               mod_txt + 5 * h, S_t, mod_stride, X_txt, h, S_t, S, ldh),
                                  st));
     } else {
       DK_TRY(dk_launch_gemm(fc1_img, st));
@@ -623,7 +633,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   for (int i = 0; i < c.depth_unified; ++i) {
     const StreamW& w = m->single[i];
     const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
-    const int M = B * S, ldcat = (1 + r) * h;
+    const int M = B * S, ldcat = m->ldcat;
     DK_TRY(dk_launch_ln_modulate(m->X, h, m->XN, h, M, h, mod, mod + h, mod_stride, S, M, 0, c.layer_norm_eps, st));
     {  // linear1: [q|k|v] -> QKV, gelu(fc1) -> CAT[:, h:], one pass over the modulated activations
       GemmParams l1 = linear_params(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, (3 + r) * h, h, DK_EPI_BIAS, nullptr, 0, 0,
@@ -639,8 +649,8 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
     if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
-    DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, ldcat, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
-                       m->X, h, M, 0, st));
+    DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, (1 + r) * h, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
+                       m->X, h, M, 0, st, ldcat));
   }
 
   // FinalLayer (mmdit.py:767-796) on the image rows

@@ -20,6 +20,7 @@ from typing import Dict
 
 import torch
 
+from . import _lib
 from .config import MMDiTConfig, VAEDecoderConfig
 
 Tensor = torch.Tensor
@@ -217,6 +218,16 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
     def put(name, t):
         out[name] = t.to(device=dev, dtype=bf).contiguous()
 
+    def put_pitched(name, t):
+        """Long-reduction weights ([h, 4h] fc2, [h, 5h] linear2): rows at the engine's pitch (dk_weight_pitch, include/dk_hip.h)."""
+        k = t.shape[1]
+        pitch = int(_lib.load().dk_weight_pitch(k))
+        if pitch != k:
+            padded = torch.zeros(t.shape[0], pitch, dtype=bf, device=dev)
+            padded[:, :k] = t.to(device=dev, dtype=bf)
+            t = padded
+        put(name, t)
+
     xw = get("x_embedder.proj.weight")
     put("x_embedder.proj.weight", xw.reshape(xw.shape[0], -1))
     put("x_embedder.proj.bias", get("x_embedder.proj.bias"))
@@ -253,13 +264,14 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
             put(prefix + ".mlp.fc1.weight", get(prefix + ".mlp.fc1.weight"))
             put(prefix + ".mlp.fc1.bias", get(prefix + ".mlp.fc1.bias"))
         if single:
-            put(prefix + ".linear2.weight",
-                torch.cat([get(prefix + ".attn.o_proj.weight").to(dev), get(prefix + ".mlp.fc2.weight").to(dev)], dim=1))
+            put_pitched(prefix + ".linear2.weight",
+                        torch.cat([get(prefix + ".attn.o_proj.weight").to(dev), get(prefix + ".mlp.fc2.weight").to(dev)], dim=1))
             put(prefix + ".linear2.bias", get(prefix + ".attn.o_proj.bias"))
         else:
-            for n in ("attn.o_proj", "mlp.fc2"):
-                put(f"{prefix}.{n}.weight", get(f"{prefix}.{n}.weight"))
-                put(f"{prefix}.{n}.bias", get(f"{prefix}.{n}.bias"))
+            put(f"{prefix}.attn.o_proj.weight", get(f"{prefix}.attn.o_proj.weight"))
+            put(f"{prefix}.attn.o_proj.bias", get(f"{prefix}.attn.o_proj.bias"))
+            put_pitched(f"{prefix}.mlp.fc2.weight", get(f"{prefix}.mlp.fc2.weight"))
+            put(f"{prefix}.mlp.fc2.bias", get(f"{prefix}.mlp.fc2.bias"))
 
     for i in range(cfg.depth_multimodal):
         skip_txt = (i == cfg.depth_multimodal - 1) and cfg.depth_unified < 1

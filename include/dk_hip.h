@@ -270,6 +270,13 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
  * unknown key. */
 int dk_tune_set(const char* key, int32_t value);
 
+/* Row pitch, in elements, the engine expects for a weight matrix whose rows hold k elements and that it reads with a long
+ * reduction: k itself below 8192, k + 64 from there on (the 24-30 KB row stride of the [h, 4h] "mlp.fc2.weight" of the
+ * double-stream blocks and the [h, 5h] "linear2.weight" of the single-stream blocks of FLUX camps on a few memory channels;
+ * the pad columns are never read).  The host packer (diffusionkit_amd/weights.py: pack_mmdit) lays those two tensors out
+ * with this pitch before dk_mmdit_bind; every other tensor is dense.  No reference counterpart (mlx arrays are dense). */
+int32_t dk_weight_pitch(int32_t k);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,7 +81,7 @@ def test_pack_mmdit_shapes():
         assert torch.equal(p[b0 + ".attn.qkv.weight"][h:2 * h], w[b0 + ".attn.k_proj.weight"])
         if cfg.depth_unified:
             s0 = "unified_transformer_blocks.0.transformer_block"
-            assert p[s0 + ".linear2.weight"].shape == (h, 5 * h)
+            assert p[s0 + ".linear2.weight"].shape == (h, 5 * h)  # below the padded-pitch threshold (dk_weight_pitch)
             assert torch.equal(p[s0 + ".linear2.weight"][:, :h], w[s0 + ".attn.o_proj.weight"])
             assert torch.equal(p[s0 + ".linear2.bias"], w[s0 + ".attn.o_proj.bias"])  # one bias (quirk Q8)
             # fused linear1 = [q | k | v | fc1] over one read of the modulated activations
@@ -130,3 +130,25 @@ def test_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_weight_pitch_rule_and_pitched_packing():
+    """dk_weight_pitch (include/dk_hip.h): dense below 8192 elements per row, +64 from there on; pack_mmdit lays the
+    fc2 / linear2 weights out at that pitch with zero pad columns (no compute: runs without a GPU)."""
+    from diffusionkit_amd import _lib
+    lib = _lib.load()
+    assert [lib.dk_weight_pitch(k) for k in (64, 6144, 8191, 8192, 12288, 15360)] == [64, 6144, 8191, 8256, 12352, 15424]
+    cfg = tiny_flux()
+    w = synth_mmdit_weights(cfg)
+    h, r = cfg.hidden_size, cfg.mlp_ratio
+    assert lib.dk_tune_set(b"pitch_min_k", 64) == 0
+    try:
+        p = pack_mmdit(cfg, w, "cpu")
+    finally:
+        assert lib.dk_tune_set(b"pitch_min_k", 8192) == 0
+    b0 = "multimodal_transformer_blocks.0.image_transformer_block.mlp.fc2.weight"
+    s0 = "unified_transformer_blocks.0.transformer_block"
+    assert p[b0].shape == (h, r * h + 64) and p[s0 + ".linear2.weight"].shape == (h, (1 + r) * h + 64)
+    assert torch.equal(p[b0][:, :r * h], w[b0]) and torch.all(p[b0][:, r * h:] == 0)
+    assert torch.equal(p[s0 + ".linear2.weight"][:, h:(1 + r) * h], w[s0 + ".mlp.fc2.weight"])
+    assert torch.all(p[s0 + ".linear2.weight"][:, (1 + r) * h:] == 0)

@@ -243,6 +243,23 @@ def test_multi_seed_batch_equals_single(dev):
     one, _ = pipe.denoise_latents(text, pooled, num_steps=2, latent_size=(8, 8), seed=6)
     assert max_abs(both[1:2], one) < 2e-2
 
+@pytest.mark.parametrize("name,cfg,B", [("flux", tiny_flux(), 2), ("sd3", tiny_sd3(), 2)])
+def test_mmdit_forward_tiny_padded_pitch(dev, name, cfg, B):
+    """dk_weight_pitch (include/dk_hip.h): fc2 / linear2 weights and the activations they multiply stored with padded rows.
+    At tiny widths the rule is forced on through the tuning knob; the result must not move."""
+    from diffusionkit_amd import ops
+    ts = [1000.0, 752.0, 500.0]
+    _, dense, _ = forward_case(cfg, dev, B, 8, 12, 20, ts, 1)
+    ops.tune("pitch_min_k", 64)
+    try:
+        eng, out, res = forward_case(cfg, dev, B, 8, 12, 20, ts, 1)
+        b0 = "multimodal_transformer_blocks.0.image_transformer_block.mlp.fc2.weight"
+        assert eng.weights[b0].shape[1] == cfg.mlp_ratio * cfg.hidden_size + 64
+    finally:
+        ops.tune("pitch_min_k", 8192)
+    yardstick_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], name)
+    assert torch.equal(out, dense)
+
 
 # ---- production widths ----------------------------------------------------------------------------
 def test_flux_width_block_pair_full_sequence(dev):
