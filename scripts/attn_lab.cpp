@@ -67,7 +67,8 @@ int main(int argc, char** argv) {
     ++idx;
     if (only_shape >= 0 && idx != only_shape) continue;
     const int h = s.H * s.D;
-    const size_t n = (size_t)s.B * s.S * 3 * h;
+    const int ld = 3 * h + (getenv("LAB_PAD") ? atoi(getenv("LAB_PAD")) : 0);  // row pitch of the packed q|k|v buffer
+    const size_t n = (size_t)s.B * s.S * ld;
     std::vector<uint16_t> hq(n);
     for (size_t i = 0; i < n; ++i) hq[i] = f2bf(nrand());
     void* qkv;
@@ -79,7 +80,7 @@ int main(int argc, char** argv) {
     const float scale = 1.0f / sqrtf((float)s.D);
     auto run = [&](int v) {
       dk_tune_set("attn", only_mode != -999 ? only_mode : modes[v]);
-      if (dk_attention_bf16(qkv, (char*)qkv + h * 2, (char*)qkv + 2 * h * 2, out[v], s.B, s.H, s.S, s.D, 3 * h, h, scale, st) != 0) {
+      if (dk_attention_bf16(qkv, (char*)qkv + h * 2, (char*)qkv + 2 * h * 2, out[v], s.B, s.H, s.S, s.D, ld, h, scale, st) != 0) {
         printf("launch failed: %s\n", dk_last_error());
         exit(1);
       }
