@@ -35,7 +35,8 @@
 
 #ifndef DK_V3_ABL
 #define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n), bit mask: 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile
-                     // barrier, 8 producers do not store, 16 finishers neither wait nor read, 32 no C stores, 64 no tail (run-time false)
+                     // barrier, 8 producers do not store, 16 finishers neither wait nor read, 32 no C stores, 64 no tail (run-time false),
+                     // 128 every K-tile's DMA re-reads K-tile 0 (same bytes into the LDS, all of them L2 hits)
 #endif
 
 // placement of the 4 DMA pieces inside a 16-MFMA step: in front of MFMA slots PH, PH + STR, ... (PH0 / PH1 for the
@@ -188,10 +189,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
     if (op == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, (int)la[hh][j],
-                                               i * (BK * 2), 0, 0);
+                                               ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, (int)lw[j],
-                                               (int)(hh * w128 + j * w8) + i * (BK * 2), 0, 0);
+                                               (int)(hh * w128 + j * w8) + ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
   };
   auto issue_tile = [&](int i) {
 #pragma unroll
