@@ -228,7 +228,9 @@ def main():
         ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")
-        if os.path.exists(pmc):  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes: those were taken on the default
+        # workload at one image per step, so the figure is attached to that configuration only
+        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         roofline = {
             "bound": "mfma", "kernel": "dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
