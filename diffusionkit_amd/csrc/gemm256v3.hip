@@ -36,7 +36,7 @@
 #ifndef DK_V3_ABL
 #define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n), bit mask: 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile
                      // barrier, 8 producers do not store, 16 finishers neither wait nor read, 32 no C stores, 64 no tail (run-time false),
-                     // 128 every K-tile's DMA re-reads K-tile 0 (same bytes into the LDS, all of them L2 hits)
+                     // 128 every K-tile's DMA re-reads K-tile 0 (same bytes into the LDS, all of them L2 hits), 256 see DK_TILE_WAIT
 #endif
 
 // placement of the 4 DMA pieces inside a 16-MFMA step: in front of MFMA slots PH, PH + STR, ... (PH0 / PH1 for the
@@ -236,6 +236,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_LDS_RD(xf##SET[2], aA_, 12288);             \
     DK_LDS_RD(xf##SET[3], aA_, 14336);             \
   } while (0)
+// the wait in front of the tile barrier: own fragment reads and own DMA pieces of the next K-tile.  (lab: 256 = the DMA
+// pieces get one more K-tile to land -- results are wrong, the timing is that of a ring with twice the window)
+#define DK_TILE_WAIT(V)                                                                                                  \
+  do {                                                                                                                   \
+    if (DK_V3_ABL & 256)                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
+    else                                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
+  } while (0)
 #define DK_WAIT4(N, V) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]))
 #define DK_WAIT8(N, V, U)                  \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" \
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_RDA_HI(1, bo, 1);                                                                                         \
     DK_WAIT8(4, wf1, xf0);                                                                                       \
     DK_MMG(1, 0, 0, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, ON1);                                   \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
+    DK_TILE_WAIT(xf1);                                                                                           \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
     DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */        \
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, 0, R);                                                               \
     DK_RDA_HI(1, bo, 1);                                                                                         \
     DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, R, 16);                                                              \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(xf1[0]), "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3])::"memory"); \
+    DK_TILE_WAIT(xf1);                                                                                           \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
     DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2, 0, R);                                                         \
@@ -354,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_RDA_LO
 #undef DK_RDA_HI
 #undef DK_WAIT4
+#undef DK_TILE_WAIT
 #undef DK_WAIT8
 #undef DK_MMG
 #undef DK_MMGR
