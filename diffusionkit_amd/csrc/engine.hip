@@ -280,6 +280,8 @@ struct dk_mmdit {
   bool prepared = false, mod_ready = false;
   // workspace views
   bf16_t *X, *XN, *QKV, *ATT, *CAT, *HID, *MOD, *POS;
+  bf16_t* CTXE = nullptr;  // context_embedder(text) [B, S_t, h], step-invariant (dk_mmdit_cache_context)
+  bool ctx_ready = false;
   int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_streamk_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
@@ -437,6 +439,7 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->HID = m->CAT;
   m->MOD = (bf16_t*)c.take((size_t)n_t * B * m->mod_rows() * h * 2);
   m->POS = (bf16_t*)c.take(m->cfg.use_pos_embed ? (size_t)S_i * h * 2 : 0);
+  m->CTXE = (bf16_t*)c.take((size_t)B * S_t * h * 2);
   m->temb = (bf16_t*)c.take((size_t)n_t * m->cfg.frequency_embed_dim * 2);
   m->t1 = (bf16_t*)c.take((size_t)n_t * h * 2);
   m->tvec = (bf16_t*)c.take((size_t)n_t * h * 2);
@@ -486,6 +489,7 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   g_linear_ws = m->GWS;
   m->prepared = true;
   m->mod_ready = false;
+  m->ctx_ready = false;
   return 0;
 }
 
@@ -538,6 +542,16 @@ static int post_sdpa_seq(dk_mmdit* m, const StreamW& w, int row_off, int S_s, co
   return 0;
 }
 
+extern "C" int dk_mmdit_cache_context(dk_mmdit* m, const void* text, void* stream) {
+  DK_REQUIRE(m && m->prepared && text, "prepare must precede cache_context");
+  const dk_mmdit_config& c = m->cfg;
+  const int M = m->B * m->S_t;
+  DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, M, 0, m->ctx_w, m->ctx_b, m->CTXE, m->h(), M, 0, M, m->h(),
+                     c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, S_(stream)));
+  m->ctx_ready = true;
+  return 0;
+}
+
 extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index, void* tokens_out,
                                 void* stream) {
   DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
@@ -551,9 +565,15 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   const bf16_t* mod_step = m->MOD + (size_t)step_index * B * R * h;
   const float scale = 1.0f / sqrtf((float)m->D());
 
-  // context_embedder (mmdit.py:195): text rows of the joint stream
-  DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, B * S_t, 0, m->ctx_w, m->ctx_b, m->X, h, S_t, S, B * S_t, h,
-                     c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
+  // context_embedder (mmdit.py:195): text rows of the joint stream -- recomputed from `text`, or copied from the
+  // step-invariant result of dk_mmdit_cache_context when `text` is null
+  if (text != nullptr) {
+    DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, B * S_t, 0, m->ctx_w, m->ctx_b, m->X, h, S_t, S, B * S_t, h,
+                       c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
+  } else {
+    DK_REQUIRE(m->ctx_ready, "forward without text needs dk_mmdit_cache_context first");
+    DK_CHECK_HIP(hipMemcpy2DAsync(m->X, (size_t)S * h * 2, m->CTXE, (size_t)S_t * h * 2, (size_t)S_t * h * 2, B, hipMemcpyDeviceToDevice, st));
+  }
   // x_embedder (+ learned positional embedding) (mmdit.py:197-206): image rows
   DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
                      c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));

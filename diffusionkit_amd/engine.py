@@ -89,6 +89,7 @@ class MMDiTEngine:
                    "dk_mmdit_prepare")
         self._shape = shape
         self._n_cached = 0
+        self._ctx_cached = False
 
     @property
     def batch(self):
@@ -122,19 +123,32 @@ class MMDiTEngine:
         self._pooled_keepalive = pooled
         self._n_cached = len(ts)
 
-    def forward_tokens(self, tokens_in: Tensor, text: Tensor, step_index: int, tokens_out: Optional[Tensor] = None) -> Tensor:
-        """MMDiT.__call__ between patchify and unpatchify (mmdit.py:188-252)."""
-        _require_cuda(tokens_in, "tokens_in", torch.bfloat16)
+    def cache_context(self, text: Tensor) -> None:
+        """Step-invariant hoist of ``context_embedder(text)`` (mmdit.py:195): embedded once here, ``forward_tokens(..., None, i)``
+        then reuses it in every step (the reference recomputes the same values per call)."""
         _require_cuda(text, "text", torch.bfloat16)
-        if tuple(tokens_in.shape) != self.tokens_shape():
-            raise _lib.DkHipError(f"tokens_in shape {tuple(tokens_in.shape)} != {self.tokens_shape()}")
         if tuple(text.shape) != (self._shape[0], self._shape[3], self.config.token_level_text_embed_dim):
             raise _lib.DkHipError(f"text shape {tuple(text.shape)} does not match the prepared problem")
+        _lib.check(self.lib.dk_mmdit_cache_context(self._h, text.data_ptr(), _stream()), "dk_mmdit_cache_context")
+        self._ctx_cached = True
+
+    def forward_tokens(self, tokens_in: Tensor, text: Optional[Tensor], step_index: int, tokens_out: Optional[Tensor] = None) -> Tensor:
+        """MMDiT.__call__ between patchify and unpatchify (mmdit.py:188-252).  ``text=None`` uses ``cache_context``'s result."""
+        _require_cuda(tokens_in, "tokens_in", torch.bfloat16)
+        if tuple(tokens_in.shape) != self.tokens_shape():
+            raise _lib.DkHipError(f"tokens_in shape {tuple(tokens_in.shape)} != {self.tokens_shape()}")
+        if text is None:
+            if not getattr(self, "_ctx_cached", False):
+                raise _lib.DkHipError("forward_tokens(text=None) needs cache_context(text) after prepare()")
+        else:
+            _require_cuda(text, "text", torch.bfloat16)
+            if tuple(text.shape) != (self._shape[0], self._shape[3], self.config.token_level_text_embed_dim):
+                raise _lib.DkHipError(f"text shape {tuple(text.shape)} does not match the prepared problem")
         if not (0 <= step_index < self._n_cached):
             raise KeyError(f"no cached modulation parameters for step {step_index}")  # reference: dict KeyError
         if tokens_out is None:
             tokens_out = torch.empty_like(tokens_in)
-        _lib.check(self.lib.dk_mmdit_forward(self._h, tokens_in.data_ptr(), text.data_ptr(), step_index,
+        _lib.check(self.lib.dk_mmdit_forward(self._h, tokens_in.data_ptr(), None if text is None else text.data_ptr(), step_index,
                                              tokens_out.data_ptr(), _stream()), "dk_mmdit_forward")
         return tokens_out
 

@@ -505,6 +505,7 @@ def sample_euler(model: CFGDenoiser, x: Tensor, sigmas, extra_args=None):
     timesteps = _round_to_dtype(pipe.sampler.timestep(sigmas), pipe.activation_dtype)
     mm.prepare(rows, x.shape[1:3], conditioning.shape[1], len(timesteps))
     model.cache_modulation_params(pooled, timesteps)
+    mm.cache_context(conditioning)  # context_embedder is step-invariant (the reference recomputes it in every call, mmdit.py:195)
 
     x = x.to(torch.float32).contiguous().clone()
     tok = mm.patchify(x, dup=2 if cfg_on else 1)
@@ -512,7 +513,7 @@ def sample_euler(model: CFGDenoiser, x: Tensor, sigmas, extra_args=None):
     iter_time = []
     for i in range(len(sigmas) - 1):
         t0 = time.perf_counter()
-        mm.forward_tokens(tok, conditioning, i, tokens_out=out)
+        mm.forward_tokens(tok, None, i, tokens_out=out)
         _euler(pipe, x, out, tok, cfg_on, float(sigmas[i]), float(sigmas[i + 1]), cfg_weight)
         torch.cuda.synchronize(pipe.device)
         iter_time.append(round(time.perf_counter() - t0, 3))

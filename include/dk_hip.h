@@ -212,9 +212,15 @@ int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t laten
 int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled, const float* timesteps_host,
                                      int32_t n, void* stream);
 
+/* Step-invariant hoist of `self.context_embedder(token_level_text_embeddings)` (mmdit.py:195, recomputed by the reference
+ * in every MMDiT.__call__): embeds `text` (bf16 [batch, S_t, text_dim]) once into the engine's workspace; later
+ * dk_mmdit_forward calls with text == NULL copy that result into the joint stream instead of recomputing it (same values).
+ * Invalidated by dk_mmdit_prepare. */
+int dk_mmdit_cache_context(dk_mmdit* m, const void* text, void* stream);
+
 /* MMDiT.__call__ (mmdit.py:188-266) between patchify and unpatchify, for cached timestep
  * `step_index` (quirk Q11: index instead of float key).
- * tokens_in: bf16 [batch, S_i, p*p*C]; text: bf16 [batch, S_t, text_dim];
+ * tokens_in: bf16 [batch, S_i, p*p*C]; text: bf16 [batch, S_t, text_dim], or NULL after dk_mmdit_cache_context;
  * tokens_out: bf16 [batch, S_i, p*p*C] (FinalLayer output). */
 int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index,
                      void* tokens_out, void* stream);

@@ -244,6 +244,27 @@ def test_multi_seed_batch_equals_single(dev):
     assert max_abs(both[1:2], one) < 2e-2
 
 @pytest.mark.parametrize("name,cfg,B", [("flux", tiny_flux(), 2), ("sd3", tiny_sd3(), 2)])
+def test_cached_context_equals_recomputed(dev, name, cfg, B):
+    """dk_mmdit_cache_context: the hoisted context_embedder result gives the same output as recomputing it per call
+    (mmdit.py:195), on every step, and a new prepare() invalidates it."""
+    eng, _ = build(cfg, dev)
+    ts = [1000.0, 752.0, 500.0]
+    text = randn(B, 20, cfg.token_level_text_embed_dim, seed=3).to(dev, BF)
+    pooled = randn(B, cfg.pooled_text_embed_dim, seed=4).to(dev)
+    eng.prepare(B, (8, 12), 20, len(ts))
+    eng.cache_modulation_params(pooled, ts)
+    tok = eng.patchify(randn(B, 8, 12, 16, seed=5).to(dev))
+    with pytest.raises(Exception, match="cache_context"):
+        eng.forward_tokens(tok, None, 0)
+    eng.cache_context(text)
+    for step in range(len(ts)):
+        assert torch.equal(eng.forward_tokens(tok, None, step), eng.forward_tokens(tok, text, step))
+    eng.prepare(B, (8, 8), 20, len(ts))
+    with pytest.raises(Exception, match="cache_context"):
+        eng.forward_tokens(eng.patchify(randn(B, 8, 8, 16, seed=5).to(dev)), None, 0)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("flux", tiny_flux(), 2), ("sd3", tiny_sd3(), 2)])
 def test_mmdit_forward_tiny_padded_pitch(dev, name, cfg, B):
     """dk_weight_pitch (include/dk_hip.h): fc2 / linear2 weights and the activations they multiply stored with padded rows.
     At tiny widths the rule is forced on through the tuning knob; the result must not move."""
