@@ -76,11 +76,22 @@ class MMDiTEngine:
             self.lib.dk_mmdit_destroy(self._h)
             self._h = None
 
+    def _check_pitched_weights(self) -> None:
+        """The engine reads the long-reduction weights at ``dk_weight_pitch`` elements per row (include/dk_hip.h); the C ABI
+        binds bare pointers, so the layout the packer produced is checked here, where the shapes are still known."""
+        h, r = self.config.hidden_size, self.config.mlp_ratio
+        for name, t in self.weights.items():
+            k = r * h if name.endswith(".mlp.fc2.weight") else (1 + r) * h if name.endswith(".linear2.weight") else 0
+            if k and t.shape[1] != self.lib.dk_weight_pitch(k):
+                raise _lib.DkHipError(f"{name}: {t.shape[1]} elements per row, the engine expects dk_weight_pitch({k}) = "
+                                      f"{self.lib.dk_weight_pitch(k)} (was the weight packed under a different pitch_min_k?)")
+
     # -- shape / workspace ---------------------------------------------------------------
     def prepare(self, batch: int, latent_size: Sequence[int], text_len: int, n_timesteps: int) -> None:
         shape = (batch, int(latent_size[0]), int(latent_size[1]), text_len, n_timesteps)
         if self._shape == shape:
             return
+        self._check_pitched_weights()
         nbytes = self.lib.dk_mmdit_workspace_bytes(self._h, *shape)
         dev = next(iter(self.weights.values())).device
         if self._ws is None or self._ws.numel() < nbytes:

@@ -66,3 +66,11 @@ def test_cli_end_to_end_tiny(tmp_path):
                            "--height", "64", "--width", "64", "-o", str(tmp_path / "c.png"), "--negative_prompt", "blurry"],
                           pipeline_overrides=over_sd3)
     assert img4.size == (64, 64) and len(log4["denoising"]["iter_time"]) == 2
+
+
+def test_module_entry_point_prints_help():
+    """``python -m diffusionkit_amd.cli --help`` works without a GPU (argument parsing happens before anything is loaded)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "diffusionkit_amd.cli", "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--model-version" in r.stdout and "--denoise" in r.stdout

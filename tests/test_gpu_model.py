@@ -280,6 +280,8 @@ def test_mmdit_forward_tiny_padded_pitch(dev, name, cfg, B):
         ops.tune("pitch_min_k", 8192)
     yardstick_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], name)
     assert torch.equal(out, dense)
+    with pytest.raises(Exception, match="dk_weight_pitch"):  # packed under another pitch rule than the engine now applies
+        eng.prepare(B, (8, 8), 20, len(ts))
 
 
 # ---- production widths ----------------------------------------------------------------------------
