@@ -61,6 +61,12 @@ def gelu_erf(x: Tensor, P: Prec) -> Tensor:
     return P.r(0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0))))
 
 
+def gelu_tanh(x: Tensor, P: Prec) -> Tensor:
+    """nn.GELU(approximate="tanh"): what the reference's PyTorch MMDiT uses (torch/mmdit.py:242) where its MLX one uses the
+    exact form; only selected by tests that replay outputs of that PyTorch module (tests/test_reference_torch_golden.py)."""
+    return P.r(torch.nn.functional.gelu(x, approximate="tanh"))
+
+
 def layer_norm(x: Tensor, eps: float) -> Tensor:
     """mx.fast.layer_norm without affine (mmdit.py:838-849), fp32 statistics."""
     mu = x.mean(dim=-1, keepdim=True)
@@ -149,10 +155,11 @@ class OracleMMDiT:
     (Linear [out,in]; x_embedder.proj.weight [out,kh,kw,in]).
     """
 
-    def __init__(self, cfg, weights: Dict[str, Tensor], prec: Optional[Prec] = None):
+    def __init__(self, cfg, weights: Dict[str, Tensor], prec: Optional[Prec] = None, gelu: str = "erf"):
         self.cfg = cfg
         self.w = weights
         self.P = prec or Prec()
+        self.gelu = {"erf": gelu_erf, "tanh": gelu_tanh}[gelu]  # "erf" = the MLX path (quirk Q3)
         # timestep embedding is evaluated in config.dtype independently of the activation
         # dtype (quirk Q2); the exact oracle keeps it exact.
         self.P_embed = Prec(embed_dtype(cfg)) if self.P.act is not None else Prec()
@@ -223,12 +230,12 @@ class OracleMMDiT:
         attn_out = self._lin(sdpa_out, prefix + ".attn.o_proj")
         if parallel_mlp:
             # fc2 bias is zeroed on every call (mmdit.py:741-742, quirk Q8)
-            h1 = gelu_erf(self._lin(inter["m"], prefix + ".mlp.fc1"), P)
+            h1 = self.gelu(self._lin(inter["m"], prefix + ".mlp.fc1"), P)
             mlp_out = linear(h1, self.w[prefix + ".mlp.fc2.weight"], None, P)
             return P.r(residual + P.r(mod[2] * P.r(attn_out + mlp_out)))
         residual = P.r(residual + P.r(attn_out * mod[2]))
         m2 = affine_transform(residual, mod[3], mod[4], cfg.layer_norm_eps, P)
-        h1 = gelu_erf(self._lin(m2, prefix + ".mlp.fc1"), P)
+        h1 = self.gelu(self._lin(m2, prefix + ".mlp.fc1"), P)
         mlp_out = self._lin(h1, prefix + ".mlp.fc2")
         return P.r(residual + P.r(mod[5] * mlp_out))
 

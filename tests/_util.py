@@ -40,3 +40,41 @@ def randn(*shape, seed=0, scale=1.0):
 #  - chained ops (block / model level): compared against the fp32 oracle with the bf16-emulating
 #    oracle as yardstick: err(hip, fp32) <= 2 * err(emu, fp32) + 2e-3.
 TOL_SINGLE_OP = 3e-3
+
+
+def seeded_checkpoint(spec, seed):
+    """Deterministic synthetic checkpoint for a list of (name, shape): matrices / conv kernels ~ N(0, 1 / fan_in), vectors that
+    scale (1-D '...norm...weight') ~ 1 + 0.1 N(0, 1), every other vector ~ 0.1 N(0, 1).  Shared by the fixture generator
+    (tests/golden/make_reference_torch_fixtures.py) and the tests that replay its checkpoints."""
+    import math
+    import torch
+    g = torch.Generator().manual_seed(int(seed))
+    out = {}
+    for name, shape in spec:
+        shape = tuple(int(s) for s in shape)
+        t = torch.randn(*shape, generator=g)
+        if len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            if name.endswith("pos_embed"):
+                t = 0.1 * t
+            else:
+                t = t / math.sqrt(fan_in)
+        elif "norm" in name and name.endswith(".weight"):
+            t = 1.0 + 0.1 * t
+        else:
+            t = 0.1 * t
+        out[name] = t
+    return out
+
+
+def checkpoint_checksum(ckpt):
+    """Order-dependent scalar digest of a checkpoint's values (float64 sum of value * running index weights)."""
+    import torch
+    acc, n = 0.0, 0
+    for name in ckpt:
+        v = ckpt[name].double().flatten()
+        acc += float((v * torch.arange(1, v.numel() + 1, dtype=torch.float64).remainder(997.0)).sum()) * (1 + n % 7)
+        n += 1
+    return acc
