@@ -4,12 +4,15 @@ PyTorch-CPU restatement of the reference's MLX MMDiT, used only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the HIP
 path.  Nothing under diffusionkit_amd/ imports this package.
 
-PARITY UNPINNED: the reference's arithmetic lives in MLX 0.17.3 (setup.py:32), which
-cannot be imported in this environment, and the reference ships no local golden
-vectors for this path (its only numeric gate is an image-PSNR check against
-network-hosted PNGs, tests/mlx/test_diffusion_pipeline.py:91-93).  This restatement is
-therefore pinned only by (a) scalar known-answer values derived from the reference's
-formulas (tests/golden/kat_scalars.json) and (b) self-consistency goldens.
+PARITY PARTLY PINNED.  The reference's arithmetic lives in MLX 0.17.3 (setup.py:32), which cannot be imported in this
+environment, and the reference ships no local golden vectors for this path (its only numeric gate is an image-PSNR check
+against network-hosted PNGs, tests/mlx/test_diffusion_pipeline.py:91-93): against MLX itself parity is UNPINNED.  What the
+restatement is pinned by: (a) outputs of the reference's OWN PyTorch modules (python/src/diffusionkit/torch/{mmdit,vae,
+model_io}.py, executed in the build container by tests/golden/make_reference_torch_fixtures.py with stand-ins for three
+absent packages, replayed by tests/test_reference_torch_golden.py: SD3 MMDiT wiring rel-L2 4e-7, VAE decoder 2e-6, both
+checkpoint key maps) -- this does not cover what only the MLX path has (FLUX blocks, RoPE, QK-norm, the exact-erf GELU, MLX's
+rounding points); (b) scalar known-answer values derived from the reference's formulas (tests/golden/kat_scalars.json);
+(c) self-consistency goldens.
 
 Each function cites the reference lines it follows
 (paths relative to python/src/diffusionkit/mlx/).

@@ -149,8 +149,8 @@ def main():
     import diffusionkit.torch.model_io as rio
     import diffusionkit.torch.vae as rvae
 
-    # ---- VAE decoder: channels (32, 32, 64, 64), 3 resnets per level, latent 8 x 12 -> image 64 x 96 ----
-    vcfg = rvae.VAEDecoderConfig(resolution=64, base_channels=32, channel_multipliers=[1, 1, 2, 2])
+    # ---- VAE decoder: channels (64, 64, 128, 128), 3 resnets per level, latent 8 x 12 -> image 64 x 96 ----
+    vcfg = rvae.VAEDecoderConfig(resolution=64, base_channels=64, channel_multipliers=[1, 1, 2, 2])
     vae = rvae.VAEDecoder(vcfg).eval()
     spec = compvis_vae_spec(vae)
     seed = 20240924
@@ -159,7 +159,7 @@ def main():
     z = torch.randn(2, 16, 8, 12, generator=torch.Generator().manual_seed(seed + 1))
     img = vae(z)
     np.savez_compressed(os.path.join(HERE, "reference_torch_vae.npz"), spec=json.dumps(spec), seed=seed, checksum=checkpoint_checksum(ckpt),
-                        z=z.numpy(), image=img.numpy(), channels=np.array([32, 32, 64, 64]), group_norm_eps=1e-6)
+                        z=z.numpy(), image=img.numpy(), channels=np.array([64, 64, 128, 128]), group_norm_eps=1e-6)
     print("vae:", tuple(img.shape), "checksum", checkpoint_checksum(ckpt))
 
     # ---- SD3 MMDiT: depth 2 (hidden 128, 2 heads of 64), latent 8 x 12, 20 text tokens, batch 2 ----
