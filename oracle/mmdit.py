@@ -4,15 +4,18 @@ PyTorch-CPU restatement of the reference's MLX MMDiT, used only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the HIP
 path.  Nothing under diffusionkit_amd/ imports this package.
 
-PARITY PARTLY PINNED.  The reference's arithmetic lives in MLX 0.17.3 (setup.py:32), which cannot be imported in this
-environment, and the reference ships no local golden vectors for this path (its only numeric gate is an image-PSNR check
-against network-hosted PNGs, tests/mlx/test_diffusion_pipeline.py:91-93): against MLX itself parity is UNPINNED.  What the
-restatement is pinned by: (a) outputs of the reference's OWN PyTorch modules (python/src/diffusionkit/torch/{mmdit,vae,
-model_io}.py, executed in the build container by tests/golden/make_reference_torch_fixtures.py with stand-ins for three
-absent packages, replayed by tests/test_reference_torch_golden.py: SD3 MMDiT wiring rel-L2 4e-7, VAE decoder 2e-6, both
-checkpoint key maps) -- this does not cover what only the MLX path has (FLUX blocks, RoPE, QK-norm, the exact-erf GELU, MLX's
-rounding points); (b) scalar known-answer values derived from the reference's formulas (tests/golden/kat_scalars.json);
-(c) self-consistency goldens.
+PARITY: WIRING PINNED, MLX ARITHMETIC UNPINNED.  The reference's arithmetic lives in MLX 0.17.3 (setup.py:32), which cannot be
+imported in this environment, and the reference ships no local golden vectors for this path (its only numeric gate is an
+image-PSNR check against network-hosted PNGs, tests/mlx/test_diffusion_pipeline.py:91-93).  What the restatement is pinned by:
+(a) outputs of the reference's OWN MLX model code -- mlx/{config,mmdit,sampler,vae}.py imported unmodified and run on a
+PyTorch-backed stand-in for the few dozen MLX operations they call (tests/golden/mlx_standin.py,
+tests/golden/make_reference_mlx_fixtures.py; replayed by tests/test_reference_mlx_golden.py): FLUX double + single blocks with
+RoPE and QK-norm at batch 1 and 2, SD3 at batch 1 and 2, the SD3.5 shape class, the modulation cache, VAE decoder and encoder,
+sampler schedules -- the exact-math oracle agrees to 2e-7 .. 4e-7 relative; (b) outputs of the reference's own PyTorch modules
+(torch/{mmdit,vae,model_io}.py, tests/golden/make_reference_torch_fixtures.py, tests/test_reference_torch_golden.py: SD3 MMDiT
+4e-7, VAE decoder 2e-6, both checkpoint key maps); (c) scalar known-answer values derived from the reference's formulas
+(tests/golden/kat_scalars.json); (d) self-consistency goldens.  What stays unpinned is what only real MLX can tell: where its
+bf16 / fp16 kernels round (the Prec(act=...) mode below is a model of that).
 
 Each function cites the reference lines it follows
 (paths relative to python/src/diffusionkit/mlx/).

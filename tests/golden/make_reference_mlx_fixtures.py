@@ -1,0 +1,156 @@
+"""Generates tests/golden/reference_mlx_*.npz by RUNNING THE REFERENCE'S OWN MLX MODEL CODE
+(/root/reference/python/src/diffusionkit/mlx/{config,mmdit,sampler}.py, imported where they lie, unmodified) on top of
+tests/golden/mlx_standin.py -- a PyTorch-backed stand-in for the few dozen MLX operations those files use (MLX itself is Apple-only
+and absent here).  Run from the repo root:  python tests/golden/make_reference_mlx_fixtures.py
+
+What executing the reference this way pins: the MMDiT's wiring for FLUX (double + single-stream blocks, RoPE tables and their
+application, QK-norm, the [text, image] joint order, the fused-bias quirk of the single blocks, reshape patchify / unpack), for SD3
+(learned positional embedding crop, conv patchify / unpatchify, [image, text] order, the skipped text stream of the last block,
+batch 1 = fused LayerNorm-modulate, batch 2 = unfused) and for the SD3.5 shape class (QK-norm without RoPE), the modulation cache
+(cache_modulation_params: keyed by timestep.item(), adaLN weights emptied afterwards), and the samplers' sigma / timestep
+schedules.  What it does not pin: MLX's own arithmetic (everything runs in float32 here, configs are built with dtype float32).
+
+Weights: seeded synthetic tensors under the reference's module-tree names (tests/_util.seeded_checkpoint over the shapes of
+diffusionkit_amd.weights.mmdit_weight_shapes); the fixtures store seed, checksum, inputs and the reference outputs.
+"""
+import importlib
+import json
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import mlx_standin  # noqa: E402
+from tests._util import checkpoint_checksum, seeded_checkpoint  # noqa: E402
+
+REF = "/root/reference/python/src/diffusionkit"
+
+
+def import_reference():
+    mx, _ = mlx_standin.install()
+    import typing
+    bt, btt = types.ModuleType("beartype"), types.ModuleType("beartype.typing")
+    for n in ("Dict", "List", "Optional", "Tuple"):
+        setattr(btt, n, getattr(typing, n))
+    bt.typing = btt
+    ax, axu = types.ModuleType("argmaxtools"), types.ModuleType("argmaxtools.utils")
+    axu.get_logger = logging.getLogger
+    ax.utils = axu
+    # the package __init__ of diffusionkit.mlx is the whole pipeline (hub, tokenizers, PIL ...): register bare packages instead so
+    # that the model files import each other (from .config import ...) without it
+    pk, pkm = types.ModuleType("diffusionkit"), types.ModuleType("diffusionkit.mlx")
+    pk.__path__, pkm.__path__ = [REF], [os.path.join(REF, "mlx")]
+    for m in (bt, btt, ax, axu, pk, pkm):
+        sys.modules[m.__name__] = m
+    rc = importlib.import_module("diffusionkit.mlx.config")
+    rm = importlib.import_module("diffusionkit.mlx.mmdit")
+    rs = importlib.import_module("diffusionkit.mlx.sampler")
+    return mx, rc, rm, rs
+
+
+def run_vae(mx, tag, model, spec, x, seed):
+    ckpt = seeded_checkpoint(spec, seed)
+    set_weights(model, ckpt, mx)
+    assert len(mlx_standin.tree_flatten(model.parameters())) == len(spec), tag
+    out = np.asarray(model(mx.array(x)))
+    np.savez_compressed(os.path.join(HERE, f"reference_mlx_{tag}.npz"), spec=json.dumps(spec), seed=seed, checksum=checkpoint_checksum(ckpt),
+                        x=x.numpy(), out=out)
+    print(f"{tag}: out {out.shape}, |out| mean {np.abs(out).mean():.4f}")
+
+
+def set_weights(module, ckpt, mx):
+    """Assign tensors by the reference's dotted names ('a.b.3.layers.1.weight')."""
+    for name, t in ckpt.items():
+        parts = name.split(".")
+        obj = module
+        for p in parts[:-1]:
+            obj = obj[int(p)] if p.isdigit() else getattr(obj, p)
+        cur = getattr(obj, parts[-1])
+        assert tuple(cur.shape) == tuple(t.shape), (name, cur.shape, t.shape)
+        setattr(obj, parts[-1], mx.array(t))
+
+
+def run_case(mx, rc, rm, ours, ref_kwargs, B, latent_hw, S_t, timesteps, step, seed, tag):
+    from diffusionkit_amd.weights import mmdit_weight_shapes
+    cfg = rc.MMDiTConfig(dtype=mx.float32, float16_dtype=mx.float32, low_memory_mode=False, **ref_kwargs)
+    model = rm.MMDiT(cfg)
+    spec = sorted((k, tuple(v)) for k, v in mmdit_weight_shapes(ours).items())
+    ckpt = seeded_checkpoint(spec, seed)
+    set_weights(model, ckpt, mx)
+    # the reference module holds one kind of tensor the engine layout does not: mlp.fc2.bias of the single-stream blocks, which the
+    # reference multiplies by zero on every call (mmdit.py:741-742).  They get NON-zero values here, so the fixture only matches
+    # an implementation that drops them as well.
+    extra = sorted({k for k, _ in mlx_standin.tree_flatten(model.parameters())} - {k for k, _ in spec})
+    assert all(k.startswith("unified_transformer_blocks.") and k.endswith(".mlp.fc2.bias") for k in extra), extra
+    set_weights(model, seeded_checkpoint([(k, (ours.hidden_size,)) for k in extra], seed + 7), mx)
+    g = torch.Generator().manual_seed(seed + 1)
+    lat = torch.randn(B, latent_hw[0], latent_hw[1], 16, generator=g)
+    text = torch.randn(B, S_t, ours.token_level_text_embed_dim, generator=g)
+    pooled = torch.randn(B, ours.pooled_text_embed_dim, generator=g)
+    ts = mx.array(np.asarray(timesteps, dtype=np.float32))
+    model.cache_modulation_params(mx.array(pooled), ts)
+    out = model(mx.array(lat), mx.array(text[:, :, None, :]), mx.array(np.full((B,), timesteps[step], dtype=np.float32)))
+    out = np.asarray(out)
+    np.savez_compressed(os.path.join(HERE, f"reference_mlx_mmdit_{tag}.npz"), spec=json.dumps(spec), seed=seed,
+                        checksum=checkpoint_checksum(ckpt), latent=lat.numpy(), text=text.numpy(), pooled=pooled.numpy(),
+                        timesteps=np.asarray(timesteps, dtype=np.float32), step=step, out=out)
+    print(f"{tag}: out {out.shape}, |out| mean {np.abs(out).mean():.4f}, checksum {checkpoint_checksum(ckpt):.6f}")
+
+
+def main():
+    torch.set_grad_enabled(False)
+    mx, rc, rm, rs = import_reference()
+    from dataclasses import replace
+    from diffusionkit_amd.config import tiny_flux, tiny_sd3
+
+    flux = tiny_flux()
+    flux_kw = dict(num_heads=flux.num_heads, depth_multimodal=flux.depth_multimodal, depth_unified=flux.depth_unified,
+                   parallel_mlp_for_unified_blocks=True, hidden_size_override=flux.hidden_size, patchify_via_reshape=True,
+                   pos_embed_type=rc.PositionalEncoding.PreSDPARope, rope_axes_dim=(16, 56, 56), use_qk_norm=True,
+                   pooled_text_embed_dim=flux.pooled_text_embed_dim, token_level_text_embed_dim=flux.token_level_text_embed_dim)
+    run_case(mx, rc, rm, flux, flux_kw, 1, (8, 12), 20, [1000.0, 752.0, 500.0], 1, 4101, "flux_b1")
+    run_case(mx, rc, rm, flux, flux_kw, 2, (8, 8), 12, [1000.0, 250.0], 1, 4102, "flux_b2")
+
+    sd3 = tiny_sd3(depth=2, heads=2, max_res=16)
+    sd3_kw = dict(num_heads=2, depth_multimodal=2, hidden_size_override=128, max_latent_resolution=16,
+                  pooled_text_embed_dim=sd3.pooled_text_embed_dim, token_level_text_embed_dim=sd3.token_level_text_embed_dim)
+    run_case(mx, rc, rm, sd3, sd3_kw, 2, (8, 12), 20, [1000.0, 857.5], 1, 4103, "sd3_b2")
+    run_case(mx, rc, rm, sd3, sd3_kw, 1, (12, 8), 9, [857.5], 0, 4104, "sd3_b1")
+
+    sd35 = replace(tiny_sd3(depth=3, heads=2, max_res=16), use_qk_norm=True)
+    sd35_kw = dict(num_heads=2, depth_multimodal=3, hidden_size_override=128, max_latent_resolution=16, use_qk_norm=True,
+                   pooled_text_embed_dim=sd35.pooled_text_embed_dim, token_level_text_embed_dim=sd35.token_level_text_embed_dim)
+    run_case(mx, rc, rm, sd35, sd35_kw, 2, (8, 8), 10, [500.0], 0, 4105, "sd35_b2")
+
+    # ---- VAE decoder and encoder (vae.py:336-467), the tiny configurations of the test suite ----
+    rv = importlib.import_module("diffusionkit.mlx.vae")
+    from diffusionkit_amd.config import tiny_vae, tiny_vae_encoder
+    from diffusionkit_amd.weights import vae_encoder_weight_shapes, vae_weight_shapes
+    dc, ec = tiny_vae(), tiny_vae_encoder()
+    g = torch.Generator().manual_seed(4200)
+    dec = rv.VAEDecoder(dc.in_channels, dc.out_channels, list(dc.block_out_channels), dc.layers_per_block, dc.resnet_groups)
+    run_vae(mx, "vae_decoder", dec, sorted((k, tuple(v)) for k, v in vae_weight_shapes(dc).items()), torch.randn(2, 8, 12, 16, generator=g), 4201)
+    enc = rv.VAEEncoder(ec.in_channels, ec.out_channels, list(ec.block_out_channels), ec.layers_per_block, ec.resnet_groups)
+    run_vae(mx, "vae_encoder", enc, sorted((k, tuple(v)) for k, v in vae_encoder_weight_shapes(ec).items()),
+            torch.rand(2, 64, 96, 3, generator=g) * 2.0 - 1.0, 4202)
+
+    # ---- samplers: the schedules the step loop indexes (sampler.py:10-77) ----
+    out = {}
+    for name, cls in (("flow", rs.ModelSamplingDiscreteFlow), ("flux", rs.FluxSampler)):
+        for shift in (1.0, 3.0):
+            s = cls(shift=shift)
+            out[f"{name}_shift{shift}_sigmas"] = np.asarray(s.sigmas, dtype=np.float64)
+            out[f"{name}_shift{shift}_timestep_of_half"] = np.asarray(s.timestep(mx.array(0.5)), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "reference_mlx_sampler.npz"), **out)
+    print("sampler:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
