@@ -11,7 +11,8 @@ image-PSNR check against network-hosted PNGs, tests/mlx/test_diffusion_pipeline.
 PyTorch-backed stand-in for the few dozen MLX operations they call (tests/golden/mlx_standin.py,
 tests/golden/make_reference_mlx_fixtures.py; replayed by tests/test_reference_mlx_golden.py): FLUX double + single blocks with
 RoPE and QK-norm at batch 1 and 2, SD3 at batch 1 and 2, the SD3.5 shape class, the modulation cache, VAE decoder and encoder,
-sampler schedules -- the exact-math oracle agrees to 2e-7 .. 4e-7 relative; (b) outputs of the reference's own PyTorch modules
+sampler schedules, and DiffusionPipeline.denoise_latents end to end (CFG, FLUX, img2img) -- the exact-math oracle agrees to
+2e-7 .. 4e-7 relative (2e-5 over whole step loops); (b) outputs of the reference's own PyTorch modules
 (torch/{mmdit,vae,model_io}.py, tests/golden/make_reference_torch_fixtures.py, tests/test_reference_torch_golden.py: SD3 MMDiT
 4e-7, VAE decoder 2e-6, both checkpoint key maps); (c) scalar known-answer values derived from the reference's formulas
 (tests/golden/kat_scalars.json); (d) self-consistency goldens.  What stays unpinned is what only real MLX can tell: where its

@@ -3,8 +3,9 @@
 Restates python/src/diffusionkit/mlx/sampler.py:10-77 and
 python/src/diffusionkit/mlx/__init__.py:253-292 (denoise_latents), :553-584
 (get_noise/get_sigmas/get_empty_latent/decode), :674-788 (CFGDenoiser, LatentFormat,
-to_d, sample_euler).  PARITY UNPINNED (see oracle/mmdit.py header); the scalar
-known-answer values in tests/golden/kat_scalars.json pin the schedule/noise helpers.
+to_d, sample_euler).  Pinned by the reference's own DiffusionPipeline.denoise_latents executed on the MLX stand-in (SD3 with
+CFG, FLUX, SD3 img2img: tests/test_reference_mlx_golden.py, rel-L2 < 2e-5) and by the scalar known-answer values in
+tests/golden/kat_scalars.json; MLX's low-precision arithmetic is unpinned (see oracle/mmdit.py header).
 """
 from __future__ import annotations
 

@@ -34,25 +34,71 @@ REF = "/root/reference/python/src/diffusionkit"
 
 
 def import_reference():
+    import huggingface_hub  # noqa: F401
+    import transformers  # noqa: F401  (both BEFORE the stand-in exists: transformers probes for an installed mlx when imported)
     mx, _ = mlx_standin.install()
     import typing
     bt, btt = types.ModuleType("beartype"), types.ModuleType("beartype.typing")
     for n in ("Dict", "List", "Optional", "Tuple"):
         setattr(btt, n, getattr(typing, n))
     bt.typing = btt
-    ax, axu = types.ModuleType("argmaxtools"), types.ModuleType("argmaxtools.utils")
+    ax, axu, axt = (types.ModuleType(n) for n in ("argmaxtools", "argmaxtools.utils", "argmaxtools.test_utils"))
     axu.get_logger = logging.getLogger
-    ax.utils = axu
-    # the package __init__ of diffusionkit.mlx is the whole pipeline (hub, tokenizers, PIL ...): register bare packages instead so
-    # that the model files import each other (from .config import ...) without it
-    pk, pkm = types.ModuleType("diffusionkit"), types.ModuleType("diffusionkit.mlx")
-    pk.__path__, pkm.__path__ = [REF], [os.path.join(REF, "mlx")]
-    for m in (bt, btt, ax, axu, pk, pkm):
+    axt.AppleSiliconContextMixin = type("AppleSiliconContextMixin", (), {})  # base classes of a benchmarking helper
+    axt.InferenceContextSpec = type("InferenceContextSpec", (), {})
+    ax.utils, ax.test_utils = axu, axt
+    for m in (bt, btt, ax, axu, axt):
         sys.modules[m.__name__] = m
-    rc = importlib.import_module("diffusionkit.mlx.config")
-    rm = importlib.import_module("diffusionkit.mlx.mmdit")
-    rs = importlib.import_module("diffusionkit.mlx.sampler")
-    return mx, rc, rm, rs
+    sys.path.insert(0, os.path.dirname(REF))
+    ref = importlib.import_module("diffusionkit.mlx")  # the reference's real package: pipeline, step loop, loaders, encoders
+    mods = {n: importlib.import_module("diffusionkit.mlx." + n) for n in ("config", "mmdit", "sampler", "vae", "clip", "t5", "tokenizer")}
+    return mx, ref, mods
+
+
+def adaln_items(model, mx):
+    """[(name, array)] of every adaLN_modulation weight and bias: what load_mmdit(only_modulation_dict=True) hands back to
+    CFGDenoiser.clear_cache (mlx/__init__.py:686-689) after cache_modulation_params has emptied them"""
+    return [(k, mx.array(v.t.clone())) for k, v in mlx_standin.tree_flatten(model.parameters()) if "adaLN_modulation" in k]
+
+
+def run_denoise(mx, ref, mods, tag, ours, ref_kwargs, flux, cfg_weight, num_steps, latent_size, S_t, seed, denoise=1.0, encoder=None):
+    """DiffusionPipeline.denoise_latents (mlx/__init__.py:253-292) itself -- get_empty_latent / get_noise / get_sigmas /
+    noise_scaling / sample_euler / CFGDenoiser / latent format -- on a pipeline object assembled without its loader."""
+    from diffusionkit_amd.weights import mmdit_weight_shapes
+    rc, rm, rs = mods["config"], mods["mmdit"], mods["sampler"]
+    cfg = rc.MMDiTConfig(dtype=mx.float32, float16_dtype=mx.float32, low_memory_mode=False, **ref_kwargs)
+    model = rm.MMDiT(cfg)
+    spec = sorted((k, tuple(v)) for k, v in mmdit_weight_shapes(ours).items())
+    ckpt = seeded_checkpoint(spec, seed)
+    set_weights(model, ckpt, mx)
+    pipe = object.__new__(ref.FluxPipeline if flux else ref.DiffusionPipeline)  # no __init__: that one downloads checkpoints
+    pipe.mmdit = model
+    pipe.sampler = rs.FluxSampler(shift=1.0) if flux else rs.ModelSamplingDiscreteFlow(shift=3.0)
+    pipe.latent_format = ref.FluxLatentFormat() if flux else ref.SD3LatentFormat()
+    pipe.activation_dtype = mx.float32
+    saved = adaln_items(model, mx)
+    pipe.load_mmdit = lambda only_modulation_dict=False: saved
+    g = torch.Generator().manual_seed(seed + 1)
+    rows = 2 if cfg_weight > 0 else 1
+    cond = torch.randn(rows, S_t, ours.token_level_text_embed_dim, generator=g)
+    pooled = torch.randn(rows, ours.pooled_text_embed_dim, generator=g)
+    extra = {}
+    image_path = None
+    if encoder is not None:
+        from PIL import Image
+        rgb = (torch.rand(latent_size[0] * 8, latent_size[1] * 8, 3, generator=g) * 255).to(torch.uint8).numpy()
+        image_path = os.path.join(HERE, f"_tmp_{tag}.png")
+        Image.fromarray(rgb).save(image_path)
+        pipe.encoder = encoder
+        extra["image"] = rgb
+    latent, _ = pipe.denoise_latents(mx.array(cond), mx.array(pooled), num_steps=num_steps, cfg_weight=cfg_weight,
+                                     latent_size=latent_size, seed=seed, image_path=image_path, denoise=denoise)
+    if image_path:
+        os.remove(image_path)
+    np.savez_compressed(os.path.join(HERE, f"reference_mlx_denoise_{tag}.npz"), spec=json.dumps(spec), seed=seed,
+                        checksum=checkpoint_checksum(ckpt), cond=cond.numpy(), pooled=pooled.numpy(), latent=np.asarray(latent),
+                        num_steps=num_steps, cfg_weight=cfg_weight, latent_size=np.asarray(latent_size), denoise=denoise, **extra)
+    print(f"denoise {tag}: latent {np.asarray(latent).shape}, |latent| mean {np.abs(np.asarray(latent)).mean():.4f}")
 
 
 def run_vae(mx, tag, model, spec, x, seed):
@@ -106,7 +152,8 @@ def run_case(mx, rc, rm, ours, ref_kwargs, B, latent_hw, S_t, timesteps, step, s
 
 def main():
     torch.set_grad_enabled(False)
-    mx, rc, rm, rs = import_reference()
+    mx, ref, mods = import_reference()
+    rc, rm, rs = mods["config"], mods["mmdit"], mods["sampler"]
     from dataclasses import replace
     from diffusionkit_amd.config import tiny_flux, tiny_sd3
 
@@ -130,7 +177,7 @@ def main():
     run_case(mx, rc, rm, sd35, sd35_kw, 2, (8, 8), 10, [500.0], 0, 4105, "sd35_b2")
 
     # ---- VAE decoder and encoder (vae.py:336-467), the tiny configurations of the test suite ----
-    rv = importlib.import_module("diffusionkit.mlx.vae")
+    rv = mods["vae"]
     from diffusionkit_amd.config import tiny_vae, tiny_vae_encoder
     from diffusionkit_amd.weights import vae_encoder_weight_shapes, vae_weight_shapes
     dc, ec = tiny_vae(), tiny_vae_encoder()
@@ -140,6 +187,11 @@ def main():
     enc = rv.VAEEncoder(ec.in_channels, ec.out_channels, list(ec.block_out_channels), ec.layers_per_block, ec.resnet_groups)
     run_vae(mx, "vae_encoder", enc, sorted((k, tuple(v)) for k, v in vae_encoder_weight_shapes(ec).items()),
             torch.rand(2, 64, 96, 3, generator=g) * 2.0 - 1.0, 4202)
+
+    # ---- the step loop: denoise_latents end to end (SD3 with CFG, FLUX without, SD3 img2img through the encoder above) ----
+    run_denoise(mx, ref, mods, "sd3_cfg", sd3, sd3_kw, False, 5.0, 3, (8, 12), 20, 4301)
+    run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)
+    run_denoise(mx, ref, mods, "sd3_img2img", sd3, sd3_kw, False, 5.0, 5, (8, 8), 20, 4303, denoise=0.6, encoder=enc)
 
     # ---- samplers: the schedules the step loop indexes (sampler.py:10-77) ----
     out = {}

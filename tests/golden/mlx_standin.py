@@ -140,6 +140,9 @@ class array:
     def square(self):
         return array(self.t * self.t)
 
+    def split(self, indices_or_sections, axis=0):
+        return split(self, indices_or_sections, axis)
+
     # -- arithmetic
     def _bin(self, other, fn, rev=False):
         o = _scalar_like(other, self.t)
@@ -192,6 +195,10 @@ def arange(start, stop=None, step=1, dtype=None):
     floaty = any(isinstance(v, float) for v in (start, stop, step))
     t = torch.arange(start, stop, step, dtype=torch.float32 if floaty else torch.int32)
     return array(t if dtype is None else t.to(dtype.t))
+
+
+def linspace(start, stop, num=50, dtype=float32):
+    return array(torch.linspace(float(start), float(stop), int(num), dtype=torch.float32).to(dtype.t))
 
 
 def zeros(shape, dtype=float32):
@@ -247,6 +254,25 @@ def pad(a, pad_width, constant_values=0):
 
 def broadcast_to(a, shape):
     return array(torch.broadcast_to(_t(a), tuple(shape)))
+
+
+def minimum(a, b):
+    return array(a)._bin(b, torch.minimum) if not isinstance(a, array) else a._bin(b, torch.minimum)
+
+
+def maximum(a, b):
+    return array(a)._bin(b, torch.maximum) if not isinstance(a, array) else a._bin(b, torch.maximum)
+
+
+def where(c, a, b):
+    ct = _t(c).bool()
+    ref = _t(a) if isinstance(a, (array, torch.Tensor)) else (_t(b) if isinstance(b, (array, torch.Tensor)) else torch.zeros(()))
+    return array(torch.where(ct, _scalar_like(a, ref), _scalar_like(b, ref)))
+
+
+abs = lambda a: array(torch.abs(_t(a)))  # noqa: A001
+zeros_like = lambda a: array(torch.zeros_like(_t(a)))
+ones_like = lambda a: array(torch.ones_like(_t(a)))
 
 
 def clip(a, lo, hi):
@@ -310,6 +336,40 @@ class _Fast:
 fast = _Fast()
 
 
+class _Random:
+    @staticmethod
+    def seed(s):
+        torch.manual_seed(int(s))
+
+    @staticmethod
+    def normal(shape=(), dtype=float32, loc=0.0, scale=1.0, key=None):
+        return array((torch.randn(*tuple(shape)) * scale + loc).to(dtype.t))
+
+
+random = _Random()
+
+
+class _Metal:  # memory bookkeeping of the Apple GPU backend: nothing to report here
+    device_info = staticmethod(lambda: {"memory_size": 0, "max_recommended_working_set_size": 0})
+    set_memory_limit = staticmethod(lambda *a, **k: 0)
+    set_cache_limit = staticmethod(lambda *a, **k: 0)
+    get_peak_memory = staticmethod(lambda: 0)
+    get_active_memory = staticmethod(lambda: 0)
+    get_cache_memory = staticmethod(lambda: 0)
+    reset_peak_memory = staticmethod(lambda: None)
+    clear_cache = staticmethod(lambda: None)
+
+
+metal = _Metal()
+int16 = Dtype("int16", torch.int16, 2)
+uint32 = Dtype("uint32", torch.int64, 4)
+_BY_TORCH[torch.int16] = int16
+
+
+def load(*a, **k):
+    raise RuntimeError("mx.load: no checkpoints in the fixture generator")
+
+
 # ---- mlx.utils ------------------------------------------------------------------------------------------------------------
 def tree_map(fn, tree, *rest):
     if isinstance(tree, dict):
@@ -317,6 +377,26 @@ def tree_map(fn, tree, *rest):
     if isinstance(tree, (list, tuple)):
         return type(tree)(tree_map(fn, v, *[r[i] for r in rest]) for i, v in enumerate(tree))
     return fn(tree, *rest)
+
+
+def tree_unflatten(items):
+    """[('a.0.b', v), ...] -> nested dicts / lists (numeric keys become list positions)"""
+    root = {}
+    for name, v in items:
+        parts = name.split(".")
+        cur = root
+        for p in parts[:-1]:
+            cur = cur.setdefault(p, {})
+        cur[parts[-1]] = v
+
+    def fix(node):
+        if not isinstance(node, dict):
+            return node
+        if node and all(k.isdigit() for k in node):
+            return [fix(node[str(i)]) if str(i) in node else {} for i in range(max(int(k) for k in node) + 1)]
+        return {k: fix(v) for k, v in node.items()}
+
+    return fix(root)
 
 
 def tree_flatten(tree, prefix=""):
@@ -405,6 +485,14 @@ class Module:
         return {k: v for k, v in self._items() if isinstance(v, (Module, list))}
 
     def eval(self):
+        return self
+
+    def load_weights(self, weights, strict=True):
+        items = list(weights.items()) if isinstance(weights, dict) else list(weights)
+        if strict:
+            have = {k for k, _ in tree_flatten(self.parameters())}
+            assert have == {k for k, _ in items}, sorted(have ^ {k for k, _ in items})[:5]
+        self.update(tree_unflatten(items))
         return self
 
     def set_dtype(self, dtype):
@@ -534,8 +622,45 @@ class Sequential(Module):
         return x
 
 
+class MultiHeadAttention(Module):
+    """mlx.nn.MultiHeadAttention: projections without bias unless asked, heads split from the last axis, additive mask."""
+
+    def __init__(self, dims, num_heads, query_input_dims=None, key_input_dims=None, value_input_dims=None, value_dims=None,
+                 value_output_dims=None, bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.query_proj = Linear(query_input_dims or dims, dims, bias=bias)
+        self.key_proj = Linear(key_input_dims or dims, dims, bias=bias)
+        self.value_proj = Linear(value_input_dims or key_input_dims or dims, value_dims or dims, bias=bias)
+        self.out_proj = Linear(value_dims or dims, value_output_dims or dims, bias=bias)
+
+    def __call__(self, queries, keys, values, mask=None):
+        q, k, v = self.query_proj(queries), self.key_proj(keys), self.value_proj(values)
+        H = self.num_heads
+        B, L, _ = q.shape
+        S = k.shape[1]
+        q = q.reshape(B, L, H, -1).transpose(0, 2, 1, 3)
+        k = k.reshape(B, S, H, -1).transpose(0, 2, 1, 3)
+        v = v.reshape(B, S, H, -1).transpose(0, 2, 1, 3)
+        o = fast.scaled_dot_product_attention(q, k, v, scale=math.sqrt(1.0 / q.shape[-1]), mask=mask)
+        return self.out_proj(o.transpose(0, 2, 1, 3).reshape(B, L, -1))
+
+
 def silu(x):
     return SiLU()(x)
+
+
+def relu(x):
+    return array(torch.relu(_t(x)))
+
+
+def gelu_fast_approx(x):
+    t = _t(x)
+    return array(t * torch.sigmoid(1.702 * t))
+
+
+def quantize(*a, **k):
+    raise RuntimeError("nn.quantize: quantised checkpoints are outside the fixture generator")
 
 
 def gelu(x):
@@ -548,15 +673,16 @@ def install():
     core = types.ModuleType("mlx.core")
     for n in ("array", "Dtype", "float32", "float16", "bfloat16", "int32", "int64", "uint8", "bool_", "arange", "zeros", "ones",
               "concatenate", "stack", "split", "repeat", "expand_dims", "pad", "broadcast_to", "clip", "softmax", "exp", "log", "sin", "cos", "sqrt",
-              "rsqrt", "sigmoid", "erf", "square", "einsum", "eval", "mean", "fast"):
+              "rsqrt", "sigmoid", "erf", "square", "einsum", "eval", "mean", "fast", "linspace", "random", "minimum", "maximum", "where",
+              "abs", "zeros_like", "ones_like", "metal", "int16", "uint32", "load"):
         setattr(core, n, getattr(me, n))
     core.float = float32  # (the reference only ever writes mx.float32 / mx.float16; kept for attribute scans)
     nn = types.ModuleType("mlx.nn")
     for n in ("Module", "Linear", "Embedding", "Conv2d", "GroupNorm", "LayerNorm", "RMSNorm", "SiLU", "GELU", "Identity", "Sequential",
-              "silu", "gelu"):
+              "silu", "gelu", "relu", "gelu_fast_approx", "MultiHeadAttention", "quantize"):
         setattr(nn, n, getattr(me, n))
     utils = types.ModuleType("mlx.utils")
-    utils.tree_map, utils.tree_flatten = tree_map, tree_flatten
+    utils.tree_map, utils.tree_flatten, utils.tree_unflatten = tree_map, tree_flatten, tree_unflatten
     mlx = types.ModuleType("mlx")
     mlx.core, mlx.nn, mlx.utils = core, nn, utils
     for m in (mlx, core, nn, utils):

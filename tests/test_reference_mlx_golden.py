@@ -119,3 +119,70 @@ def test_hip_vae_engines_match_reference_mlx_model_code():
     ckpt, x, want = _vae_case("vae_encoder")
     mom = VAEEncoderEngine(tiny_vae_encoder(), pack_vae(tiny_vae_encoder(), ckpt, dev)).encode(x.to(dev))
     assert rel_l2(want, mom.float().cpu()) < 3e-2 and psnr(want, mom.float().cpu()) > 35.0
+
+
+DENOISE = {"sd3_cfg": ("sd3_b2", False, 3.0), "flux": ("flux_b1", True, 1.0), "sd3_img2img": ("sd3_b2", False, 3.0)}
+
+
+def _denoise_case(tag):
+    f = np.load(os.path.join(GOLD, f"reference_mlx_denoise_{tag}.npz"), allow_pickle=False)
+    spec = [(k, tuple(s)) for k, s in json.loads(str(f["spec"]))]
+    ckpt = seeded_checkpoint(spec, int(f["seed"]))
+    assert abs(checkpoint_checksum(ckpt) - float(f["checksum"])) < 1e-6 * abs(float(f["checksum"])), "seeded checkpoint drifted"
+    return f, ckpt
+
+
+@pytest.mark.parametrize("tag", sorted(DENOISE))
+def test_oracle_step_loop_matches_reference_denoise_latents(tag):
+    """DiffusionPipeline.denoise_latents (mlx/__init__.py:253-292) executed by the reference itself: empty latent, numpy noise,
+    sigma schedule, noise scaling, CFGDenoiser, sample_euler, latent format -- and, for img2img, read_image -> VAE encoder ->
+    posterior sample -> process_in -> truncated schedule."""
+    from oracle import pipeline as op
+    cfg_name, flux, shift = DENOISE[tag]
+    cfg = CASES[cfg_name]
+    f, ckpt = _denoise_case(tag)
+    model = OracleMMDiT(cfg, ckpt, Prec())
+    init = None
+    if "image" in f.files:
+        from diffusionkit_amd.config import tiny_vae_encoder
+        from oracle.vae import OracleVAEEncoder
+        eck, _, _ = _vae_case("vae_encoder")  # the encoder the generator handed to the reference pipeline
+        init = op.encode_image_to_latents(OracleVAEEncoder(tiny_vae_encoder(), eck, Prec()), op.read_image_array(f["image"]), int(f["seed"]))
+    got = op.denoise_latents(model, torch.from_numpy(f["cond"]), torch.from_numpy(f["pooled"]), int(f["num_steps"]),
+                             float(f["cfg_weight"]), tuple(int(v) for v in f["latent_size"]), int(f["seed"]), shift, flux, Prec(),
+                             init_latent=init, denoise=float(f["denoise"]))
+    want = torch.from_numpy(f["latent"])
+    assert got.shape == want.shape
+    assert rel_l2(want, got) < 2e-5, rel_l2(want, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["sd3_cfg", "flux"])
+def test_hip_pipeline_matches_reference_denoise_latents(tag):
+    """The HIP pipeline's denoise_latents (bf16 engine, fp32 latent state) against the latent the reference's own denoise_latents
+    computed in float32 from the same weights, conditioning and seed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from diffusionkit_amd.config import tiny_vae
+    from diffusionkit_amd.pipeline import DiffusionPipeline, FluxPipeline
+    from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_vae_weights
+    from oracle import pipeline as op
+    cfg_name, flux, shift = DENOISE[tag]
+    cfg = CASES[cfg_name]
+    f, ckpt = _denoise_case(tag)
+    dev = torch.device("cuda", 0)
+    packed = {"mmdit": pack_mmdit(cfg, ckpt, dev), "vae_decoder": pack_vae(tiny_vae(), synth_vae_weights(tiny_vae(), seed=1), dev)}
+    cls = FluxPipeline if flux else DiffusionPipeline
+    mv = "argmaxinc/mlx-FLUX.1-schnell" if flux else "argmaxinc/mlx-stable-diffusion-3-medium"
+    cond, pooled = torch.from_numpy(f["cond"]), torch.from_numpy(f["pooled"])
+    pipe = cls(w16=True, a16=True, shift=shift, model_version=mv, mmdit_config=cfg, vae_config=tiny_vae(), device=dev,
+               text_len=cond.shape[1], packed_weights=packed)
+    n, w, size, seed = int(f["num_steps"]), float(f["cfg_weight"]), tuple(int(v) for v in f["latent_size"]), int(f["seed"])
+    lat, _ = pipe.denoise_latents(cond.to(dev, torch.bfloat16), pooled.to(dev, torch.bfloat16), num_steps=n, cfg_weight=w,
+                                  latent_size=size, seed=seed)
+    want = torch.from_numpy(f["latent"])
+    emu = op.denoise_latents(OracleMMDiT(cfg, ckpt, Prec(torch.bfloat16)), cond, pooled, n, w, size, seed, shift, flux, Prec(torch.bfloat16))
+    e_emu, e_hip = rel_l2(want, emu), rel_l2(want, lat.float().cpu())
+    assert e_hip <= 2.0 * e_emu + 2e-3, (e_hip, e_emu)
+    p_emu, p_hip = psnr(want, emu), psnr(want, lat.float().cpu())
+    assert p_hip > min(35.0, p_emu - 1.5), (p_hip, p_emu)
