@@ -306,7 +306,9 @@ class Tokenizer:
         self.pad_to_max_length = True
         self.max_length = 77
         self.pad_with_eos = pad_with_eos
-        self._cache = {self.bos: [self.bos], self.eos: [self.eos]}
+        # a literal "<|startoftext|>" / "<|endoftext|>" inside a prompt: the reference caches the STRING as the merge result and then
+        # iterates it, i.e. the marker falls apart into single characters (tokenizer.py:29, :103) -- mirrored
+        self._cache = {self.bos: list(self.bos), self.eos: list(self.eos)}
 
     @classmethod
     def from_files(cls, vocab_json: str, merges_txt: str, pad_with_eos: bool = False) -> "Tokenizer":

@@ -3,9 +3,9 @@
 PyTorch-CPU restatement of the reference's CLIP text encoders
 (python/src/diffusionkit/mlx/clip.py:28-120), its T5 encoder (python/src/diffusionkit/mlx/t5.py:14-243,
 316-325) and the conditioning assembly of encode_text (python/src/diffusionkit/mlx/__init__.py:197-251
-for SD3, :642-671 for FLUX).  PARITY UNPINNED against MLX (see oracle/mmdit.py header); the exact-math mode is
-pinned against Hugging Face transformers' CLIPTextModelWithProjection / T5EncoderModel, the upstream both the
-reference and this restatement follow (tests/test_text_oracle.py).  Weights use the reference's names
+for SD3, :642-671 for FLUX).  The exact-math mode is pinned against the reference's own clip.py / t5.py / tokenizer.py executed on
+the MLX stand-in (tests/test_reference_mlx_golden.py, < 5e-6) and against Hugging Face transformers' CLIPTextModelWithProjection /
+T5EncoderModel, the upstream both follow (tests/test_text_oracle.py); MLX's low-precision arithmetic is unpinned (oracle/mmdit.py header).  Weights use the reference's names
 (model_io.py:565-646).
 """
 from __future__ import annotations

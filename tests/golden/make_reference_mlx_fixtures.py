@@ -188,6 +188,61 @@ def main():
     run_vae(mx, "vae_encoder", enc, sorted((k, tuple(v)) for k, v in vae_encoder_weight_shapes(ec).items()),
             torch.rand(2, 64, 96, 3, generator=g) * 2.0 - 1.0, 4202)
 
+    # ---- text encoders (clip.py:62-120, t5.py:316-325): the tiny configurations of the test suite, exact math ----
+    from transformers import T5Config
+    from diffusionkit_amd import text as tx
+    for tag, tcfg in (("clip_quick", tx.tiny_clip("quick_gelu", None)), ("clip_gelu_proj", tx.tiny_clip("gelu", 64))):
+        rcfg = rc.CLIPTextModelConfig(num_layers=tcfg.num_layers, model_dims=tcfg.model_dims, num_heads=tcfg.num_heads,
+                                      max_length=tcfg.max_length, vocab_size=tcfg.vocab_size, projection_dim=tcfg.projection_dim,
+                                      hidden_act=tcfg.hidden_act)
+        model = mods["clip"].CLIPTextModel(rcfg)
+        spec = sorted((k, tuple(v)) for k, v in tx.synth_clip_weights(tcfg, shapes_only=True).items())
+        ckpt = seeded_checkpoint(spec, 4400)
+        set_weights(model, ckpt, mx)
+        assert len(mlx_standin.tree_flatten(model.parameters())) == len(spec), tag
+        gt = torch.Generator().manual_seed(4401)
+        tokens = torch.randint(1, tcfg.vocab_size - 1, (2, 16), generator=gt)
+        tokens[0, 9], tokens[1, 13] = tcfg.vocab_size - 1, tcfg.vocab_size - 1  # EOS = the largest id (clip.py:94)
+        out = model(mx.array(tokens.numpy().astype(np.int32)))
+        np.savez_compressed(os.path.join(HERE, f"reference_mlx_{tag}.npz"), spec=json.dumps(spec), seed=4400, checksum=checkpoint_checksum(ckpt),
+                            tokens=tokens.numpy(), pooled=np.asarray(out.pooled_output), last=np.asarray(out.last_hidden_state),
+                            hidden_m2=np.asarray(out.hidden_states[-2]))
+        print(f"{tag}: pooled {np.asarray(out.pooled_output).shape}")
+    t5c = tx.tiny_t5()
+    hf = T5Config(vocab_size=t5c.vocab_size, d_model=t5c.d_model, d_kv=t5c.d_kv, num_heads=t5c.num_heads, d_ff=t5c.d_ff,
+                  num_layers=t5c.num_layers, relative_attention_num_buckets=t5c.relative_attention_num_buckets,
+                  relative_attention_max_distance=t5c.relative_attention_max_distance, layer_norm_epsilon=t5c.layer_norm_epsilon,
+                  feed_forward_proj="gated-gelu")
+    t5 = mods["t5"].SD3T5Encoder(hf, low_memory_mode=False)
+    spec = sorted((k, tuple(v)) for k, v in tx.synth_t5_weights(t5c, shapes_only=True).items())
+    ckpt = seeded_checkpoint(spec, 4410)
+    set_weights(t5, ckpt, mx)
+    assert len(mlx_standin.tree_flatten(t5.parameters())) == len(spec), "t5"
+    tokens = torch.randint(0, t5c.vocab_size, (2, 24), generator=torch.Generator().manual_seed(4411))
+    out = np.asarray(t5(mx.array(tokens.numpy().astype(np.int32))))
+    np.savez_compressed(os.path.join(HERE, "reference_mlx_t5.npz"), spec=json.dumps(spec), seed=4410, checksum=checkpoint_checksum(ckpt),
+                        tokens=tokens.numpy(), out=out)
+    print("t5:", out.shape)
+
+    # ---- CLIP byte-pair tokenizer (tokenizer.py:14-118) on a hand-made vocabulary ----
+    chars = list("abcdefghijklmnopqrstuvwxyz0123456789'.,!?-<|>")
+    merges = [("t", "h"), ("th", "e</w>"), ("c", "a"), ("ca", "t</w>"), ("a", "n"), ("an", "d</w>"), ("d", "o"), ("do", "g</w>"),
+              ("'", "s</w>"), ("i", "n"), ("in", "g</w>"), ("e", "r"), ("o", "n</w>"), ("s", "t"), ("st", "a"), ("!", "!</w>")]
+    toks = chars + [c + "</w>" for c in chars] + [a + b for a, b in merges]
+    vocab = {t: i for i, t in enumerate(dict.fromkeys(toks))}
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    ranks = {m: i for i, m in enumerate(merges)}
+    texts = ["the cat and the dog", "The  CAT's   dog!!", "a photo of 2 cats, sitting on the star-ing dog's nose?", "xyz",
+             "doing nothing " * 40, "<|startoftext|>the cat<|endoftext|>", "it's 42."]
+    out = {}
+    for pad_eos in (False, True):
+        tk = mods["tokenizer"].Tokenizer(ranks, vocab, pad_with_eos=pad_eos)
+        out[str(pad_eos)] = {"ids": [tk.tokenize(t) for t in texts], "no_specials": tk.tokenize(texts[0], prepend_bos=False, append_eos=False),
+                             "batch": tk.tokenize(texts[:2])}
+    json.dump({"vocab": vocab, "merges": merges, "texts": texts, "out": out}, open(os.path.join(HERE, "reference_mlx_tokenizer.json"), "w"))
+    print("tokenizer:", [len(i) for i in out["False"]["ids"]])
+
     # ---- the step loop: denoise_latents end to end (SD3 with CFG, FLUX without, SD3 img2img through the encoder above) ----
     run_denoise(mx, ref, mods, "sd3_cfg", sd3, sd3_kw, False, 5.0, 3, (8, 12), 20, 4301)
     run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)

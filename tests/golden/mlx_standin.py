@@ -86,7 +86,7 @@ class array:
 
     def __getitem__(self, idx):
         if isinstance(idx, tuple):
-            idx = tuple(_t(i) if isinstance(i, array) else i for i in idx)
+            idx = tuple(_t(i).long() if isinstance(i, array) else i for i in idx)
         elif isinstance(idx, array):
             idx = idx.t.long()
         return array(self.t[idx])
@@ -139,6 +139,9 @@ class array:
 
     def square(self):
         return array(self.t * self.t)
+
+    def argmax(self, axis=None, keepdims=False):
+        return array((self.t.argmax() if axis is None else self.t.argmax(dim=axis, keepdim=keepdims)).int())
 
     def split(self, indices_or_sections, axis=0):
         return split(self, indices_or_sections, axis)

@@ -186,3 +186,46 @@ def test_hip_pipeline_matches_reference_denoise_latents(tag):
     assert e_hip <= 2.0 * e_emu + 2e-3, (e_hip, e_emu)
     p_emu, p_hip = psnr(want, emu), psnr(want, lat.float().cpu())
     assert p_hip > min(35.0, p_emu - 1.5), (p_hip, p_emu)
+
+
+def _text_case(tag):
+    f = np.load(os.path.join(GOLD, f"reference_mlx_{tag}.npz"), allow_pickle=False)
+    spec = [(k, tuple(s)) for k, s in json.loads(str(f["spec"]))]
+    ckpt = seeded_checkpoint(spec, int(f["seed"]))
+    assert abs(checkpoint_checksum(ckpt) - float(f["checksum"])) < 1e-6 * abs(float(f["checksum"])), "seeded checkpoint drifted"
+    return f, ckpt
+
+
+@pytest.mark.parametrize("tag,act,proj", [("clip_quick", "quick_gelu", None), ("clip_gelu_proj", "gelu", 64)])
+def test_oracle_clip_matches_reference_mlx_model_code(tag, act, proj):
+    """CLIPTextModel (clip.py:62-120) run by the reference itself: causal mask, EOS pooling by argmax, optional projection."""
+    from diffusionkit_amd import text as tx
+    from oracle.text import OracleCLIPText
+    f, ckpt = _text_case(tag)
+    pooled, last, hidden = OracleCLIPText(tx.tiny_clip(act, proj), ckpt, Prec())(torch.from_numpy(f["tokens"]))
+    for want, got in ((f["pooled"], pooled), (f["last"], last), (f["hidden_m2"], hidden[-2])):
+        assert rel_l2(torch.from_numpy(want), got) < 5e-6
+
+
+def test_oracle_t5_matches_reference_mlx_model_code():
+    """SD3T5Encoder (t5.py:316-325): relative-position buckets, fp32 residual stream, RMSNorm, gated GELU."""
+    from diffusionkit_amd import text as tx
+    from oracle.text import OracleT5Encoder
+    f, ckpt = _text_case("t5")
+    got = OracleT5Encoder(tx.tiny_t5(), ckpt, Prec())(torch.from_numpy(f["tokens"]))
+    assert rel_l2(torch.from_numpy(f["out"]), got) < 5e-6
+
+
+def test_clip_tokenizer_matches_reference_tokenizer():
+    """Tokenizer.tokenize (tokenizer.py:14-118) run by the reference on a hand-made vocabulary: case folding, whitespace collapse,
+    the split pattern (contractions, digits one by one, punctuation runs), greedy lowest-rank merges, truncation to 75 + BOS / EOS."""
+    from diffusionkit_amd.text import Tokenizer
+    f = json.load(open(os.path.join(GOLD, "reference_mlx_tokenizer.json")))
+    ranks = {tuple(m): i for i, m in enumerate(f["merges"])}
+    for pad_eos in (False, True):
+        tk = Tokenizer(ranks, f["vocab"], pad_with_eos=pad_eos)
+        want = f["out"][str(pad_eos)]
+        assert [tk.tokenize(t) for t in f["texts"]] == want["ids"]
+        assert tk.tokenize(f["texts"][0], prepend_bos=False, append_eos=False) == want["no_specials"]
+        assert tk.tokenize(f["texts"][:2]) == want["batch"]
+    assert max(len(i) for i in want["ids"]) == 77
