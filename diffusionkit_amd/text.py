@@ -380,13 +380,14 @@ class T5Tokenizer:
 
 def tokenize_rows(tokenizer, text: str, negative_text: Optional[str] = None) -> torch.Tensor:
     """DiffusionPipeline._tokenize (mlx/__init__.py:176-195): prompt (padded to max_length when the tokenizer asks for it)
-    and, when given, the negative prompt, right-padded to a common length with EOS (CLIP-L) or 0."""
+    and the negative prompt ("" when none is given), right-padded to a common length with EOS (CLIP-L) or 0."""
     pad = tokenizer.eos_token if tokenizer.pad_with_eos else 0
     rows = [list(tokenizer.tokenize(text))]
     if tokenizer.pad_to_max_length:
         rows[0].extend([pad] * (tokenizer.max_length - len(rows[0])))
-    if negative_text is not None:
-        rows.append(list(tokenizer.tokenize(negative_text)))
+    # the reference turns a missing negative prompt into "" FIRST and then tests for None (:177-178, :187): the second row is
+    # always there -- the empty prompt when cfg_weight <= 1 -- which is what the CFG batch of two needs for 0 < cfg_weight <= 1
+    rows.append(list(tokenizer.tokenize("" if negative_text is None else negative_text)))
     n = max(len(r) for r in rows)
     return torch.tensor([r + [pad] * (n - len(r)) for r in rows], dtype=torch.long)
 

@@ -243,6 +243,43 @@ def main():
     json.dump({"vocab": vocab, "merges": merges, "texts": texts, "out": out}, open(os.path.join(HERE, "reference_mlx_tokenizer.json"), "w"))
     print("tokenizer:", [len(i) for i in out["False"]["ids"]])
 
+    # ---- encode_text (mlx/__init__.py:176-251 SD3, :642-671 FLUX) on pipelines assembled from the pieces above ----
+    class WordT5Tokenizer:  # stands in for the sentencepiece T5 tokenizer (a download): one id per word, EOS = 1, like T5
+        pad_with_eos, pad_to_max_length = False, True
+
+        def __init__(self, max_length):
+            self.max_length = max_length
+
+        def tokenize(self, s):
+            return [2 + (sum(map(ord, w)) % 300) for w in s.split()][: self.max_length - 1] + [1]
+
+    def clip_model(tcfg, seed):
+        rcfg = rc.CLIPTextModelConfig(num_layers=tcfg.num_layers, model_dims=tcfg.model_dims, num_heads=tcfg.num_heads,
+                                      max_length=tcfg.max_length, vocab_size=tcfg.vocab_size, projection_dim=tcfg.projection_dim,
+                                      hidden_act=tcfg.hidden_act)
+        m = mods["clip"].CLIPTextModel(rcfg)
+        set_weights(m, seeded_checkpoint(sorted((k, tuple(v)) for k, v in tx.synth_clip_weights(tcfg, shapes_only=True).items()), seed), mx)
+        return m
+
+    from dataclasses import replace as dc_replace
+    cl, cg = dc_replace(tx.tiny_clip("quick_gelu", None), vocab_size=len(vocab)), dc_replace(tx.tiny_clip("gelu", 64), vocab_size=len(vocab))
+    enc_out = {}
+    pipe = object.__new__(ref.DiffusionPipeline)
+    pipe.tokenizer_l = mods["tokenizer"].Tokenizer(ranks, vocab, pad_with_eos=True)
+    pipe.tokenizer_g = mods["tokenizer"].Tokenizer(ranks, vocab, pad_with_eos=False)
+    pipe.clip_l, pipe.clip_g, pipe.use_t5 = clip_model(cl, 4500), clip_model(cg, 4501), False
+    for name, cfgw, neg in (("sd3_cfg5", 5.0, "the dog"), ("sd3_cfg1", 1.0, "the dog")):
+        c, p_ = pipe.encode_text("the cat and the dog's star", cfgw, neg)
+        enc_out[name + "_cond"], enc_out[name + "_pooled"] = np.asarray(c), np.asarray(p_)
+    fp = object.__new__(ref.FluxPipeline)
+    fp.model_version = "argmaxinc/mlx-FLUX.1-schnell"
+    fp.tokenizer_l, fp.clip_l = pipe.tokenizer_l, pipe.clip_l
+    fp.t5_tokenizer, fp.t5_encoder = WordT5Tokenizer(ref.T5_MAX_LENGTH[fp.model_version]), t5
+    c, p_ = fp.encode_text("the cat and the dog's star", 0.0, "ignored")
+    enc_out["flux_cond"], enc_out["flux_pooled"] = np.asarray(c), np.asarray(p_)
+    np.savez_compressed(os.path.join(HERE, "reference_mlx_encode_text.npz"), **enc_out)
+    print("encode_text:", {k: v.shape for k, v in enc_out.items()})
+
     # ---- the step loop: denoise_latents end to end (SD3 with CFG, FLUX without, SD3 img2img through the encoder above) ----
     run_denoise(mx, ref, mods, "sd3_cfg", sd3, sd3_kw, False, 5.0, 3, (8, 12), 20, 4301)
     run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)

@@ -84,12 +84,18 @@ class array:
         for i in range(self.t.shape[0]):
             yield array(self.t[i])
 
-    def __getitem__(self, idx):
+    @staticmethod
+    def _index(idx):
         if isinstance(idx, tuple):
-            idx = tuple(_t(i).long() if isinstance(i, array) else i for i in idx)
-        elif isinstance(idx, array):
-            idx = idx.t.long()
-        return array(self.t[idx])
+            return tuple(_t(i).long() if isinstance(i, array) else i for i in idx)
+        return idx.t.long() if isinstance(idx, array) else idx
+
+    def __getitem__(self, idx):
+        return array(self.t[self._index(idx)])
+
+    def __setitem__(self, idx, value):
+        self.t = self.t.clone()
+        self.t[self._index(idx)] = _scalar_like(value, self.t).to(self.t.dtype)
 
     def item(self):
         return self.t.item()

@@ -162,5 +162,6 @@ def test_sd3_conditioning_assembly(dev, tmp_path):
     yardstick(c.float(), res["emu"][0], res["fp32"][0], "sd3 conditioning")
     yardstick(p.float(), res["emu"][1], res["fp32"][1], "sd3 pooled")
     assert torch.all(c[:, :, 256:] == 0) and torch.all(c[:, 77:] == 0)
-    c1, p1 = cond("the cat", cfg_weight=0.0)  # no negative row without CFG (:203-204)
-    assert c1.shape == (1, 154, 4096) and p1.shape == (1, 160)
+    c1, p1 = cond("the cat", cfg_weight=0.0)  # cfg_weight <= 1: the second row is still there, built from "" (:177-187)
+    assert c1.shape == (2, 154, 4096) and p1.shape == (2, 160)
+    assert torch.equal(c1[0], c[0]) and not torch.equal(c1[1], c[1])

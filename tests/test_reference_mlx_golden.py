@@ -229,3 +229,40 @@ def test_clip_tokenizer_matches_reference_tokenizer():
         assert tk.tokenize(f["texts"][0], prepend_bos=False, append_eos=False) == want["no_specials"]
         assert tk.tokenize(f["texts"][:2]) == want["batch"]
     assert max(len(i) for i in want["ids"]) == 77
+
+
+def test_encode_text_assembly_matches_reference():
+    """DiffusionPipeline.encode_text / FluxPipeline.encode_text (mlx/__init__.py:176-251, :642-671) executed by the reference on
+    pipelines assembled from its own tokenizer and CLIP / T5 models: the negative row that is always there ("" for cfg <= 1),
+    EOS / zero padding, hidden_states[-2], the 4096-wide zero padding, the T5 half (zeros without T5), FLUX's single row."""
+    from dataclasses import replace as dc_replace
+    from diffusionkit_amd import text as tx
+    from oracle.text import OracleCLIPText, OracleT5Encoder, flux_conditioning, sd3_conditioning
+    tk = json.load(open(os.path.join(GOLD, "reference_mlx_tokenizer.json")))
+    ranks, vocab = {tuple(m): i for i, m in enumerate(tk["merges"])}, tk["vocab"]
+    tok_l, tok_g = tx.Tokenizer(ranks, vocab, pad_with_eos=True), tx.Tokenizer(ranks, vocab, pad_with_eos=False)
+
+    def clip(tcfg, seed):
+        spec = sorted((k, tuple(v)) for k, v in tx.synth_clip_weights(tcfg, shapes_only=True).items())
+        return OracleCLIPText(tcfg, seeded_checkpoint(spec, seed), Prec())
+
+    cl = clip(dc_replace(tx.tiny_clip("quick_gelu", None), vocab_size=len(vocab)), 4500)
+    cg = clip(dc_replace(tx.tiny_clip("gelu", 64), vocab_size=len(vocab)), 4501)
+    f = np.load(os.path.join(GOLD, "reference_mlx_encode_text.npz"))
+    text = "the cat and the dog's star"
+    for name, cfgw, neg in (("sd3_cfg5", 5.0, "the dog"), ("sd3_cfg1", 1.0, "the dog")):
+        n = neg if cfgw > 1 else None
+        cond, pooled = sd3_conditioning(cl, cg, None, tx.tokenize_rows(tok_l, text, n), tx.tokenize_rows(tok_g, text, n), None)
+        assert cond.shape == f[name + "_cond"].shape
+        assert rel_l2(torch.from_numpy(f[name + "_cond"]), cond) < 5e-6 and rel_l2(torch.from_numpy(f[name + "_pooled"]), pooled) < 5e-6
+
+    class WordT5Tokenizer:  # the generator's stand-in for the sentencepiece tokenizer
+        pad_with_eos, pad_to_max_length, max_length = False, True, 256
+
+        def tokenize(self, s):
+            return [2 + (sum(map(ord, w)) % 300) for w in s.split()][: self.max_length - 1] + [1]
+
+    _, t5ck = _text_case("t5")
+    t5 = OracleT5Encoder(tx.tiny_t5(), t5ck, Prec())
+    cond, pooled = flux_conditioning(cl, t5, tx.tokenize_rows(tok_l, text, None), tx.tokenize_rows(WordT5Tokenizer(), text, None), 256)
+    assert rel_l2(torch.from_numpy(f["flux_cond"]), cond) < 5e-6 and rel_l2(torch.from_numpy(f["flux_pooled"]), pooled) < 5e-6

@@ -100,8 +100,9 @@ def test_tokenize_rows_padding(tmp_path):
     tg = Tokenizer.from_files(vp, mp, pad_with_eos=False)
     rows = tokenize_rows(tl, "the cat", "dog")
     assert rows.shape == (2, 77) and int(rows[0, 4]) == tl.eos_token and int(rows[1, -1]) == tl.eos_token  # EOS padding (CLIP-L)
-    rows = tokenize_rows(tg, "the cat", None)
-    assert rows.shape == (1, 77) and int(rows[0, 4]) == 0  # zero padding (CLIP-G), mlx/__init__.py:179-182
+    rows = tokenize_rows(tg, "the cat", None)  # no negative prompt = the empty prompt: the reference always builds the second row
+    assert rows.shape == (2, 77) and int(rows[0, 4]) == 0  # zero padding (CLIP-G), mlx/__init__.py:179-182
+    assert rows[1, :2].tolist() == [tg.bos_token, tg.eos_token] and int(rows[1, 2:].abs().sum()) == 0
 
 
 def test_conditioning_assembly_shapes():
