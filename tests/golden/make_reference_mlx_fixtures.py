@@ -243,6 +243,51 @@ def main():
     json.dump({"vocab": vocab, "merges": merges, "texts": texts, "out": out}, open(os.path.join(HERE, "reference_mlx_tokenizer.json"), "w"))
     print("tokenizer:", [len(i) for i in out["False"]["ids"]])
 
+    # ---- checkpoint key maps (model_io.py:130-563): BFL-FLUX / Stability-SD3 / CompVis-VAE layouts through the reference's own
+    # *_state_dict_adjustments; the adjusted dict must load STRICTLY into the reference's module tree, and its per-tensor digests
+    # are what this repository's loaders (diffusionkit_amd/model_io.py) have to reproduce from the same source checkpoint ----
+    from tests.test_model_io import to_bfl_flux, to_compvis_vae, to_compvis_vae_encoder, to_sai_sd3
+    from diffusionkit_amd.weights import mmdit_weight_shapes
+    rio = importlib.import_module("diffusionkit.mlx.model_io")
+
+    def digest(t):
+        v = torch.as_tensor(np.asarray(t), dtype=torch.float64).flatten()
+        return [list(np.asarray(t).shape), float((v * (torch.arange(v.numel(), dtype=torch.float64) % 613 + 1)).sum())]
+
+    def named(ours_cfg, seed, shapes):
+        return seeded_checkpoint(sorted((k, tuple(v)) for k, v in shapes.items()), seed)
+
+    maps = {}
+    w = named(flux, 4600, mmdit_weight_shapes(flux))
+    adj = rio.flux_state_dict_adjustments({k: mx.array(v) for k, v in to_bfl_flux(w, flux).items()}, hidden_size=flux.hidden_size,
+                                          mlp_ratio=flux.mlp_ratio)
+    m = rm.MMDiT(rc.MMDiTConfig(dtype=mx.float32, float16_dtype=mx.float32, low_memory_mode=False, **flux_kw))
+    m.update(mlx_standin.tree_unflatten(mlx_standin.tree_flatten(adj)))  # load_flux (model_io.py:784): keys the module lacks are ignored
+    have = {k for k, _ in mlx_standin.tree_flatten(m.parameters())}
+    assert all(k.endswith("k_proj.bias") for k in set(adj) - have), sorted(set(adj) - have)[:6]  # the k bias of the BFL qkv (quirk Q9)
+    assert all(k.endswith("mlp.fc2.bias") for k in have - set(adj)), sorted(have - set(adj))[:6]  # zeroed on every call (Q8)
+    maps["flux"] = {"seed": 4600, "tensors": {k: digest(v) for k, v in adj.items() if k in have}}
+    w = named(sd3, 4601, mmdit_weight_shapes(sd3))
+    # called the way load_mmdit calls it (model_io.py:726-729): the lstrip-by-character-set of that prefix and its "al_layer" repair
+    # (:316, :330-332) only work out for keys that carry "model.diffusion_model."
+    src = {k: v for k, v in to_sai_sd3(w, sd3, prefix="model.diffusion_model.").items() if not k.startswith("text_encoders.")}
+    adj = rio.mmdit_state_dict_adjustments({k: mx.array(v) for k, v in src.items()}, prefix="model.diffusion_model.")
+    m = rm.MMDiT(rc.MMDiTConfig(dtype=mx.float32, float16_dtype=mx.float32, low_memory_mode=False, **sd3_kw))
+    m.load_weights([(k, v) for k, v in adj.items()], strict=True)
+    maps["sd3"] = {"seed": 4601, "tensors": {k: digest(v) for k, v in adj.items()}}
+    w = named(dc, 4602, vae_weight_shapes(dc))
+    adj = rio.vae_decoder_state_dict_adjustments({k: mx.array(v) for k, v in to_compvis_vae(w, dc, prefix="decoder.").items()})
+    rv.VAEDecoder(dc.in_channels, dc.out_channels, list(dc.block_out_channels), dc.layers_per_block, dc.resnet_groups).load_weights(
+        [(k, v) for k, v in adj.items()], strict=True)
+    maps["vae_decoder"] = {"seed": 4602, "tensors": {k: digest(v) for k, v in adj.items()}}
+    w = named(ec, 4603, vae_encoder_weight_shapes(ec))
+    adj = rio.vae_encoder_state_dict_adjustments({k: mx.array(v) for k, v in to_compvis_vae_encoder(w, "encoder.").items()})
+    rv.VAEEncoder(ec.in_channels, ec.out_channels, list(ec.block_out_channels), ec.layers_per_block, ec.resnet_groups).load_weights(
+        [(k, v) for k, v in adj.items()], strict=True)
+    maps["vae_encoder"] = {"seed": 4603, "tensors": {k: digest(v) for k, v in adj.items()}}
+    json.dump(maps, open(os.path.join(HERE, "reference_mlx_keymaps.json"), "w"))
+    print("keymaps:", {k: len(v["tensors"]) for k, v in maps.items()})
+
     # ---- encode_text (mlx/__init__.py:176-251 SD3, :642-671 FLUX) on pipelines assembled from the pieces above ----
     class WordT5Tokenizer:  # stands in for the sentencepiece T5 tokenizer (a download): one id per word, EOS = 1, like T5
         pad_with_eos, pad_to_max_length = False, True

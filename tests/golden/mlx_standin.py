@@ -456,6 +456,8 @@ class Module:
 
     def update(self, params):
         def apply(holder, key, val):
+            if not isinstance(holder, list) and key not in vars(holder):
+                return  # mlx.nn.Module.update only touches what the module already has (a k_proj.bias for a bias-free Linear is dropped)
             cur = holder[key] if isinstance(holder, list) else getattr(holder, key)
             if isinstance(val, array):
                 if isinstance(holder, list):

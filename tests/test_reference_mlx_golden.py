@@ -266,3 +266,38 @@ def test_encode_text_assembly_matches_reference():
     t5 = OracleT5Encoder(tx.tiny_t5(), t5ck, Prec())
     cond, pooled = flux_conditioning(cl, t5, tx.tokenize_rows(tok_l, text, None), tx.tokenize_rows(WordT5Tokenizer(), text, None), 256)
     assert rel_l2(torch.from_numpy(f["flux_cond"]), cond) < 5e-6 and rel_l2(torch.from_numpy(f["flux_pooled"]), pooled) < 5e-6
+
+
+def test_checkpoint_key_maps_match_reference_adjustments():
+    """flux_state_dict_adjustments / mmdit_state_dict_adjustments / vae_{decoder,encoder}_state_dict_adjustments
+    (model_io.py:130-563) run by the reference on synthetic BFL-FLUX / Stability-SD3 / CompVis checkpoints (and loaded strictly
+    into its module trees): this repository's loaders must produce the same names, shapes and values from the same files."""
+    from diffusionkit_amd.config import tiny_vae, tiny_vae_encoder
+    from diffusionkit_amd.model_io import (load_mmdit_checkpoint, load_vae_decoder_checkpoint, load_vae_encoder_checkpoint)
+    from diffusionkit_amd.weights import mmdit_weight_shapes, vae_encoder_weight_shapes, vae_weight_shapes
+    from tests.test_model_io import to_bfl_flux, to_compvis_vae, to_compvis_vae_encoder, to_sai_sd3
+    maps = json.load(open(os.path.join(GOLD, "reference_mlx_keymaps.json")))
+
+    def digest(t):
+        v = t.double().flatten()
+        return [list(t.shape), float((v * (torch.arange(v.numel(), dtype=torch.float64) % 613 + 1)).sum())]
+
+    def check(tag, got, allowed_extra=lambda k: False):
+        want = maps[tag]["tensors"]
+        assert set(got) <= set(want) and all(allowed_extra(k) for k in set(want) - set(got)), sorted(set(want) ^ set(got))[:6]
+        for k, t in got.items():
+            shape, val = digest(t)
+            assert shape == want[k][0], (k, shape, want[k][0])
+            assert abs(val - want[k][1]) <= 1e-9 * max(1.0, abs(want[k][1])), k
+
+    def named(shapes, seed):
+        return seeded_checkpoint(sorted((k, tuple(v)) for k, v in shapes.items()), seed)
+
+    flux, sd3 = CASES["flux_b1"], CASES["sd3_b2"]
+    check("flux", load_mmdit_checkpoint(to_bfl_flux(named(mmdit_weight_shapes(flux), maps["flux"]["seed"]), flux), flux),
+          allowed_extra=lambda k: k.startswith("unified_transformer_blocks.") and k.endswith(".mlp.fc2.bias"))  # zeroed per call (Q8)
+    check("sd3", load_mmdit_checkpoint(to_sai_sd3(named(mmdit_weight_shapes(sd3), maps["sd3"]["seed"]), sd3), sd3))
+    dc, ec = tiny_vae(), tiny_vae_encoder()
+    check("vae_decoder", load_vae_decoder_checkpoint(to_compvis_vae(named(vae_weight_shapes(dc), maps["vae_decoder"]["seed"]), dc), dc))
+    check("vae_encoder", load_vae_encoder_checkpoint(to_compvis_vae_encoder(named(vae_encoder_weight_shapes(ec), maps["vae_encoder"]["seed"]),
+                                                                             "encoder."), ec))
