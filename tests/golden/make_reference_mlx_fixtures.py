@@ -325,6 +325,28 @@ def main():
     np.savez_compressed(os.path.join(HERE, "reference_mlx_encode_text.npz"), **enc_out)
     print("encode_text:", {k: v.shape for k, v in enc_out.items()})
 
+    # ---- generate_image itself (mlx/__init__.py:294-534): prompt -> tokens -> CLIP-L / CLIP-G -> conditioning -> step loop with
+    # CFG -> VAE decoder -> clip(x / 2 + 0.5) -> uint8, on an SD3 pipeline assembled from the reference's own parts ----
+    e2e = dc_replace(tiny_sd3(depth=2, heads=2, max_res=16), token_level_text_embed_dim=4096, pooled_text_embed_dim=128 + 64)
+    e2e_kw = dict(num_heads=2, depth_multimodal=2, hidden_size_override=128, max_latent_resolution=16, pooled_text_embed_dim=192,
+                  token_level_text_embed_dim=4096)
+    mm_e2e = rm.MMDiT(rc.MMDiTConfig(dtype=mx.float32, float16_dtype=mx.float32, low_memory_mode=False, **e2e_kw))
+    spec_e2e = sorted((k, tuple(v)) for k, v in mmdit_weight_shapes(e2e).items())
+    set_weights(mm_e2e, seeded_checkpoint(spec_e2e, 4700), mx)
+    gp = object.__new__(ref.DiffusionPipeline)
+    gp.mmdit, gp.decoder, gp.encoder = mm_e2e, dec, enc
+    gp.clip_l, gp.clip_g, gp.tokenizer_l, gp.tokenizer_g = pipe.clip_l, pipe.clip_g, pipe.tokenizer_l, pipe.tokenizer_g
+    gp.use_t5, gp.t5, gp.use_clip_g, gp.low_memory_mode = False, None, True, False
+    gp.activation_dtype = mx.float32
+    gp.sampler, gp.latent_format = rs.ModelSamplingDiscreteFlow(shift=3.0), ref.SD3LatentFormat()
+    saved_e2e = adaln_items(mm_e2e, mx)
+    gp.load_mmdit = lambda only_modulation_dict=False: saved_e2e
+    img, log = gp.generate_image("the cat and the dog's star", num_steps=3, cfg_weight=5.0, negative_text="the dog", latent_size=(8, 12),
+                                 seed=11, verbose=False)
+    np.savez_compressed(os.path.join(HERE, "reference_mlx_generate_image.npz"), image=np.asarray(img), seed_mmdit=4700,
+                        n_iter=len(log["denoising"]["iter_time"]))
+    print("generate_image:", np.asarray(img).shape, np.asarray(img).dtype, "mean", float(np.asarray(img).mean()))
+
     # ---- the step loop: denoise_latents end to end (SD3 with CFG, FLUX without, SD3 img2img through the encoder above) ----
     run_denoise(mx, ref, mods, "sd3_cfg", sd3, sd3_kw, False, 5.0, 3, (8, 12), 20, 4301)
     run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)

@@ -301,3 +301,37 @@ def test_checkpoint_key_maps_match_reference_adjustments():
     check("vae_decoder", load_vae_decoder_checkpoint(to_compvis_vae(named(vae_weight_shapes(dc), maps["vae_decoder"]["seed"]), dc), dc))
     check("vae_encoder", load_vae_encoder_checkpoint(to_compvis_vae_encoder(named(vae_encoder_weight_shapes(ec), maps["vae_encoder"]["seed"]),
                                                                              "encoder."), ec))
+
+
+def test_oracle_text_to_image_matches_reference_generate_image():
+    """DiffusionPipeline.generate_image (mlx/__init__.py:294-534) executed by the reference on an SD3 pipeline assembled from its own
+    tokenizer, CLIP models, MMDiT and VAE decoder: prompt -> uint8 image.  The oracle's composition of the same stages must give
+    the same image (float32 round-off may move a value across a truncation boundary: at most 1 LSB on a handful of samples)."""
+    from dataclasses import replace as dc_replace
+    from diffusionkit_amd import text as tx
+    from diffusionkit_amd.config import tiny_vae
+    from diffusionkit_amd.weights import mmdit_weight_shapes
+    from oracle import pipeline as op
+    from oracle.text import OracleCLIPText, sd3_conditioning
+    from oracle.vae import OracleVAEDecoder, decode_latents_to_image, to_uint8
+    f = np.load(os.path.join(GOLD, "reference_mlx_generate_image.npz"))
+    tk = json.load(open(os.path.join(GOLD, "reference_mlx_tokenizer.json")))
+    ranks, vocab = {tuple(m): i for i, m in enumerate(tk["merges"])}, tk["vocab"]
+    tok_l, tok_g = tx.Tokenizer(ranks, vocab, pad_with_eos=True), tx.Tokenizer(ranks, vocab, pad_with_eos=False)
+
+    def clip(tcfg, seed):
+        return OracleCLIPText(tcfg, seeded_checkpoint(sorted((k, tuple(v)) for k, v in tx.synth_clip_weights(tcfg, shapes_only=True).items()), seed), Prec())
+
+    cl = clip(dc_replace(tx.tiny_clip("quick_gelu", None), vocab_size=len(vocab)), 4500)
+    cg = clip(dc_replace(tx.tiny_clip("gelu", 64), vocab_size=len(vocab)), 4501)
+    text, neg = "the cat and the dog's star", "the dog"
+    cond, pooled = sd3_conditioning(cl, cg, None, tx.tokenize_rows(tok_l, text, neg), tx.tokenize_rows(tok_g, text, neg), None)
+    cfg = dc_replace(tiny_sd3(depth=2, heads=2, max_res=16), token_level_text_embed_dim=4096, pooled_text_embed_dim=192)
+    mm = OracleMMDiT(cfg, seeded_checkpoint(sorted((k, tuple(v)) for k, v in mmdit_weight_shapes(cfg).items()), int(f["seed_mmdit"])), Prec())
+    latent = op.denoise_latents(mm, cond, pooled, 3, 5.0, (8, 12), 11, 3.0, False, Prec())
+    dck, _, _ = _vae_case("vae_decoder")
+    img = to_uint8(decode_latents_to_image(OracleVAEDecoder(tiny_vae(), dck, Prec()), latent)).numpy()
+    want = f["image"]
+    assert img.reshape(want.shape).shape == want.shape and int(f["n_iter"]) == 3
+    diff = np.abs(img.reshape(want.shape).astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
