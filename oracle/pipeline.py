@@ -144,6 +144,17 @@ def denoise_latents(model: OracleMMDiT, conditioning: Tensor, pooled: Tensor, nu
     return process_out(latent, "flux" if flux else "sd3")
 
 
+def image_psnr(reference_u8: np.ndarray, proxy_u8: np.ndarray) -> float:
+    """python/src/diffusionkit/utils.py:52-67, the metric behind the reference's 20 dB image gate
+    (tests/mlx/test_diffusion_pipeline.py:91-93): the arrays stay uint8, so the difference WRAPS modulo 256 before it is squared
+    (and the square again), the peak is the reference's largest value and 'mse' is an RMSE."""
+    reference = np.asarray(reference_u8, dtype=np.uint8).flatten()
+    proxy = np.asarray(proxy_u8, dtype=np.uint8).flatten()
+    peak = np.abs(reference).max()
+    rmse = np.sqrt(np.mean((reference - proxy) ** 2))
+    return float(20 * np.log10((peak + 1e-5) / (rmse + 1e-10)))
+
+
 def compute_psnr(reference: np.ndarray, proxy: np.ndarray) -> float:
     """python/src/diffusionkit/utils.py:70-82 (note: 'mse' there is an RMSE)."""
     reference = np.asarray(reference, dtype=np.float64).flatten()

@@ -352,6 +352,19 @@ def main():
     run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)
     run_denoise(mx, ref, mods, "sd3_img2img", sd3, sd3_kw, False, 5.0, 5, (8, 8), 20, 4303, denoise=0.6, encoder=enc)
 
+    # ---- the reference's quality metrics (python/src/diffusionkit/utils.py:52-82): compute_psnr on float arrays, image_psnr on
+    # PIL images (whose uint8 difference wraps modulo 256 before it is squared) ----
+    from PIL import Image
+    ru = importlib.import_module("diffusionkit.utils")
+    gq = torch.Generator().manual_seed(4800)
+    a = torch.rand(32, 48, 3, generator=gq)
+    b = (a + 0.03 * torch.randn(32, 48, 3, generator=gq)).clamp(0, 1)
+    a8, b8 = (a * 255).to(torch.uint8).numpy(), (b * 255).to(torch.uint8).numpy()
+    np.savez_compressed(os.path.join(HERE, "reference_psnr.npz"), a=a.numpy(), b=b.numpy(), a8=a8, b8=b8,
+                        compute_psnr=float(ru.compute_psnr(a.numpy(), b.numpy())),
+                        image_psnr=float(ru.image_psnr(Image.fromarray(a8), Image.fromarray(b8))))
+    print("psnr:", float(ru.compute_psnr(a.numpy(), b.numpy())), float(ru.image_psnr(Image.fromarray(a8), Image.fromarray(b8))))
+
     # ---- samplers: the schedules the step loop indexes (sampler.py:10-77) ----
     out = {}
     for name, cls in (("flow", rs.ModelSamplingDiscreteFlow), ("flux", rs.FluxSampler)):

@@ -335,3 +335,13 @@ def test_oracle_text_to_image_matches_reference_generate_image():
     assert img.reshape(want.shape).shape == want.shape and int(f["n_iter"]) == 3
     diff = np.abs(img.reshape(want.shape).astype(np.int16) - want.astype(np.int16))
     assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
+def test_psnr_definitions_match_reference_utils():
+    """compute_psnr / image_psnr of python/src/diffusionkit/utils.py evaluated by the reference (the latter is its image gate and
+    works on uint8 arrays whose differences wrap)."""
+    from oracle import pipeline as op
+    f = np.load(os.path.join(GOLD, "reference_psnr.npz"))
+    assert abs(op.compute_psnr(f["a"], f["b"]) - float(f["compute_psnr"])) < 1e-4  # the reference evaluates it in float32
+    assert abs(op.image_psnr(f["a8"], f["b8"]) - float(f["image_psnr"])) < 1e-9
+    assert abs(psnr(torch.from_numpy(f["a"]), torch.from_numpy(f["b"])) - float(f["compute_psnr"])) < 1e-3  # the tests' own helper
