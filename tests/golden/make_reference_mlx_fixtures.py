@@ -352,6 +352,16 @@ def main():
     run_denoise(mx, ref, mods, "flux", flux, flux_kw, True, 0.0, 4, (8, 8), 12, 4302)
     run_denoise(mx, ref, mods, "sd3_img2img", sd3, sd3_kw, False, 5.0, 5, (8, 8), 20, 4303, denoise=0.6, encoder=enc)
 
+    # ---- read_image (mlx/__init__.py:536-551): sizes cut to multiples of 64 through a LANCZOS resize, RGBA -> RGB, [-1, 1] ----
+    from PIL import Image as PILImage
+    rgba = (torch.rand(100, 150, 4, generator=torch.Generator().manual_seed(4900)) * 255).to(torch.uint8).numpy()
+    tmp = os.path.join(HERE, "_tmp_read_image.png")
+    PILImage.fromarray(rgba).save(tmp)
+    ri = np.asarray(ref.DiffusionPipeline.read_image(object.__new__(ref.DiffusionPipeline), tmp))
+    os.remove(tmp)
+    np.savez_compressed(os.path.join(HERE, "reference_mlx_read_image.npz"), rgba=rgba, out=ri)
+    print("read_image:", ri.shape)
+
     # ---- the reference's quality metrics (python/src/diffusionkit/utils.py:52-82): compute_psnr on float arrays, image_psnr on
     # PIL images (whose uint8 difference wraps modulo 256 before it is squared) ----
     from PIL import Image

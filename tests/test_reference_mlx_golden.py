@@ -345,3 +345,17 @@ def test_psnr_definitions_match_reference_utils():
     assert abs(op.compute_psnr(f["a"], f["b"]) - float(f["compute_psnr"])) < 1e-4  # the reference evaluates it in float32
     assert abs(op.image_psnr(f["a8"], f["b8"]) - float(f["image_psnr"])) < 1e-9
     assert abs(psnr(torch.from_numpy(f["a"]), torch.from_numpy(f["b"])) - float(f["compute_psnr"])) < 1e-3  # the tests' own helper
+
+
+def test_read_image_matches_reference(tmp_path):
+    """DiffusionPipeline.read_image (mlx/__init__.py:536-551) executed by the reference on a 150 x 100 RGBA file: cut to 128 x 64 by a
+    LANCZOS resize, alpha dropped, scaled to [-1, 1], batch axis in front."""
+    import types
+    from PIL import Image
+    from diffusionkit_amd.pipeline import DiffusionPipeline
+    f = np.load(os.path.join(GOLD, "reference_mlx_read_image.npz"))
+    p = str(tmp_path / "in.png")
+    Image.fromarray(f["rgba"]).save(p)
+    got = DiffusionPipeline.read_image(types.SimpleNamespace(device="cpu"), p)
+    assert tuple(got.shape) == f["out"].shape == (1, 64, 128, 3)
+    assert np.array_equal(got.numpy(), f["out"])
