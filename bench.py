@@ -4,9 +4,13 @@
 weight broadcast at load, no collectives in the step loop).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...                      (spawns the N ranks itself when not started by a launcher)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one synthetic input per rank: 4 denoising steps (MMDiT
+Other BASELINE.json lines: --workload sd3-medium-1024 (configs[2]), --workload flux-dev-1024 --fp8 (configs[3]),
+--batch 8 on 8 GPUs (configs[4]: 64 images per step over the node).
+
+A "step" is one pass of the hot path over one synthetic input per rank: the denoising steps (MMDiT
 forward + fused CFG/Euler update) followed by the VAE latent decode to a uint8 image.  Inputs
 (conditioning, weights) are resident in HBM before the timed region; the per-image noise draw is the
 reference's host numpy RNG (mlx/__init__.py:553-557) and its 1 MiB upload is inside the region.
@@ -16,6 +20,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_FP8_TFLOPS = 5000.0   # same table: dense fp8 (block-scaled K = 128 form)
 
 
 def block_flops(S, h):
@@ -59,38 +65,79 @@ def vae_flops(vcfg, h, w):
     return f
 
 
-def cpu_baseline(cfg, S_t, S_i, num_steps, image_flops, mmdit_flops_per_step):
-    """CPU 'port' baseline: the oracle restatement timed on this box's host cores over a bounded
-    sample -- one double block + one single block of the FLUX MMDiT at the full 1024x1024 shapes
-    (S = 4352, h = 3072, fp32) -- extrapolated to the whole image by algorithmic FLOPs."""
+def cpu_baseline(image_flops, budget_s=30.0):
+    """CPU 'port' baseline: the oracle restatement timed on this box's host cores on BASELINE.json configs[0] -- the
+    configuration the reference itself runs on a CPU: SD3-medium (all 24 blocks), latent 64 x 64, CFG off, 77 + 512 text
+    tokens, Euler steps + the VAE decode, END TO END through the oracle's own denoise loop.  Bounded: Euler steps are added
+    while the projected time stays inside ``budget_s`` (at least one step + the decode); the measured FLOP rate is converted
+    to images/s of THIS bench's workload by algorithmic FLOPs."""
     import torch
-    from dataclasses import replace
-    from diffusionkit_amd.weights import synth_mmdit_weights
+    from diffusionkit_amd.config import SD3_2b, VAEDecoderConfig
+    from diffusionkit_amd.weights import synth_mmdit_weights, synth_vae_weights
+    from oracle import pipeline as op
     from oracle.mmdit import OracleMMDiT, Prec
+    from oracle.vae import OracleVAEDecoder
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    c1 = replace(cfg, depth_multimodal=1, depth_unified=1 if cfg.depth_unified else 0)
-    w = {k: v.float() for k, v in synth_mmdit_weights(c1, seed=1).items()}
-    m = OracleMMDiT(c1, w, Prec())
+    threads = min(cores, 64)  # torch's CPU GEMMs stop scaling (and the elementwise ops regress) beyond a few dozen threads
+    torch.set_num_threads(threads)
+    cfg, vcfg = SD3_2b, VAEDecoderConfig()
+    w = {k: v.float() for k, v in synth_mmdit_weights(cfg, seed=1).items()}
+    vw = {k: v.float() for k, v in synth_vae_weights(vcfg, seed=2).items()}
     g = torch.Generator().manual_seed(0)
-    p = cfg.patch_size
-    side = int(round(S_i ** 0.5)) * p
-    lat = torch.randn(1, side, side, 16, generator=g)
+    S_t, latent = 77 + 512, (64, 64)
     text = torch.randn(1, S_t, cfg.token_level_text_embed_dim, generator=g)
     pooled = torch.randn(1, cfg.pooled_text_embed_dim, generator=g)
-    m.cache_modulation_params(pooled, torch.tensor([752.0]))
+    model = OracleMMDiT(cfg, w, Prec())
+    S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
+    step_fl, dec_fl = mmdit_step_flops(cfg, S_t, S_i, 1), vae_flops(vcfg, *latent)
+    # one Euler step first (through the oracle's step loop), to size the sample
     t0 = time.perf_counter()
-    m(lat, text, 752.0)
-    dt = time.perf_counter() - t0
-    sample_flops = mmdit_step_flops(c1, S_t, S_i, 1)
-    rate = sample_flops / dt  # FLOP/s of the port on this host
+    lat = op.denoise_latents(model, text, pooled, 1, 0.0, latent, 0, 3.0, False, Prec(torch.bfloat16), t_act=Prec(torch.float16))
+    t_step = time.perf_counter() - t0
+    n_steps = 1
+    if 4 * t_step < budget_s * 0.7:  # the whole of configs[0] fits: run it as specified (4 steps), discarding the sizing step
+        t0 = time.perf_counter()
+        lat = op.denoise_latents(model, text, pooled, 4, 0.0, latent, 0, 3.0, False, Prec(torch.bfloat16), t_act=Prec(torch.float16))
+        t_den, n_steps = time.perf_counter() - t0, 4
+    else:
+        t_den = t_step
+    t0 = time.perf_counter()
+    OracleVAEDecoder(vcfg, vw, Prec())(lat)
+    t_dec = time.perf_counter() - t0
+    total_s = t_den + t_dec
+    flops = n_steps * step_fl + dec_fl
+    rate = flops / total_s
+    full_s = (4 * step_fl + dec_fl) / rate if n_steps != 4 else total_s
     return {
-        "value": rate / image_flops, "unit": "images/s", "cores": cores, "kind": "port",
-        "sample": f"oracle fp32 MMDiT with 1 double + {c1.depth_unified} single block at S={S_t + S_i}, h={cfg.hidden_size} "
-                  f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {rate / 1e9:.0f} GFLOP/s), extrapolated by FLOPs to "
-                  f"{num_steps} steps + VAE ({image_flops / 1e12:.1f} TFLOP/image)",
-        "sample_seconds": round(dt, 2),
+        "value": rate / image_flops, "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": f"oracle (fp32, PyTorch CPU, {threads} threads of {cores} cores) on BASELINE configs[0] end to end: SD3-medium 24 blocks, latent 64x64, "
+                  f"589 text tokens, {n_steps} of 4 Euler steps + VAE decode = {flops / 1e12:.2f} TFLOP in {total_s:.1f} s "
+                  f"({rate / 1e9:.0f} GFLOP/s; configs[0] image: {full_s:.1f} s{'' if n_steps == 4 else ' projected'} = {1.0 / full_s:.4f} images/s); "
+                  f"value = that FLOP rate / this workload's {image_flops / 1e12:.1f} TFLOP per image",
+        "sample_seconds": round(total_s + (t_step if n_steps == 4 else 0.0), 2),
+        "configs0_images_per_s": round(1.0 / full_s, 5),
     }
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on
+    127.0.0.1) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
 
 
 def main():
@@ -100,19 +147,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "flux-dev-1024", "tiny"])
     ap.add_argument("--batch", type=int, default=1,
-                    help="images per rank and step, denoised in one batched step loop (FLUX workloads; default 1 = BASELINE configs[1])")
+                    help="images per rank and step, denoised in one batched step loop (FLUX workloads; default 1 = BASELINE configs[1]; "
+                         "8 on 8 GPUs = configs[4])")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) weights + MX-fp8 activations on the block-scaled fp8 MFMA (BASELINE configs[3])")
+    ap.add_argument("--guidance-embed", action="store_true",
+                    help="FLUX.1-dev guidance embedding on (config FLUX_DEV); off = the reference's behaviour, which runs dev on the schnell preset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="dk_tune_set knob for A/B runs, e.g. --tune gemm_sched=0 (default kernels otherwise)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+
+    from dataclasses import replace
+
     import numpy as np
     import torch
     import torch.distributed as dist
     from diffusionkit_amd import _lib
     from diffusionkit_amd import dist as dk
-    from diffusionkit_amd.config import FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, tiny_flux, tiny_vae
+    from diffusionkit_amd.config import FLUX_DEV, FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, tiny_flux, tiny_vae
     from diffusionkit_amd.pipeline import DiffusionPipeline, FluxPipeline
     from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
 
@@ -130,9 +186,9 @@ def main():
         cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 4, 0.0, 1.0, 256, 1
     elif args.workload == "flux-dev-1024":
-        # BASELINE configs[3] shape (50 steps, 512 text tokens) with bf16 weights: the fp8-weight variant is not built;
-        # like the reference (quirk Q7) FLUX.1-dev runs without its guidance embedding
-        cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-dev"
+        # BASELINE configs[3] shape: 50 steps, 512 text tokens; like the reference (quirk Q7) FLUX.1-dev runs without its guidance
+        # embedding unless --guidance-embed
+        cfg, vcfg, cls, mv = (FLUX_DEV if args.guidance_embed else FLUX_SCHNELL), VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-dev"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 0.0, 1.0, 512, 1
     elif args.workload == "sd3-medium-1024":
         cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
@@ -140,6 +196,9 @@ def main():
     else:
         cfg, vcfg, cls, mv = tiny_flux(), tiny_vae(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (16, 16), 4, 0.0, 1.0, 64, 1
+    if args.fp8:
+        assert cfg.is_flux and args.workload != "tiny", "--fp8 is offered for the FLUX workloads (head_dim 128, token counts multiples of 128)"
+        cfg = replace(cfg, weight_dtype="fp8_e4m3")
 
     # ---- weights: rank 0 creates them, one RCCL broadcast of the packed blob over xGMI ----
     t0 = time.perf_counter()
@@ -167,8 +226,6 @@ def main():
 
     B = args.batch
     assert B >= 1 and (B == 1 or rows == 1), "--batch > 1 is offered for the FLUX workloads (one conditioning row per image)"
-    if B > 1:
-        cond, pooled = cond.repeat(B, 1, 1), pooled.repeat(B, 1)
 
     denoise_ms, vae_ms = [], []
 
@@ -206,70 +263,90 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events on the launch stream ----
+    # ---- roofline of the dominant kernel (the block Linears' MFMA GEMM), HIP events on the launch stream ----
     S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
     step_flops = mmdit_step_flops(cfg, S_t, S_i, rows)  # per image
     image_flops = num_steps * step_flops + vae_flops(vcfg, *latent)
     roofline = None
     if not args.no_roofline and rank == 0:
+        # the replay is bounded (at most 4 images: a 50-step image alone is ~10 000 launches); every launch of it is recorded
+        # (the event pool grows on demand and dk_profile_read fails if a launch was dropped)
+        n_replay = min(args.steps, 4)
         lib.dk_profile_enable(1)
         t1 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n_replay):
             one_image(rank * 100000 + i)
         torch.cuda.synchronize()
         instr = time.perf_counter() - t1
         stats = {}
-        for name, cls_id in (("gemm", 0), ("conv", 1), ("attention", 2)):
+        for name, cls_id in (("gemm", 0), ("conv", 1), ("attention", 2), ("gemm_fp8", 3)):
             ms, work, n = C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dk_profile_read(cls_id, C.byref(ms), C.byref(work), C.byref(n)), "dk_profile_read")
             stats[name] = (ms.value, work.value, n.value)
         lib.dk_profile_enable(0)
-        ms, work, n = stats["gemm"]
+        dom = "gemm_fp8" if args.fp8 else "gemm"
+        peak = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
+        ms, work, n = stats[dom]
         ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes: those were taken on the default
-        # workload at one image per step, so the figure is attached to that configuration only
-        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
+        # from the committed rocprofv3 --pmc passes over this same command (default workload, one image per step) and is attached
+        # to that configuration only
+        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1 and not args.fp8:
+            pj = json.load(open(pmc))
+            traffic, traffic_src = pj.get("hbm_bytes_per_launch"), pj.get("source", "profiles/pmc_gemm_traffic.json")
+
+        def sub(name, pk=PEAK_BF16_TFLOPS):
+            t_ms, wk, cnt = stats[name]
+            a = wk / max(t_ms, 1e-9) / 1e9
+            return {"achieved": round(a, 1), "frac": round(a / pk, 4), "ms_per_image": round(t_ms / n_replay / B, 2), "launches": cnt}
+
         roofline = {
-            "bound": "mfma", "kernel": "dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "bound": "mfma",
+            "kernel": ("dk_gemm256f8_kernel (e4m3 x e4m3 block-scaled 16x16x128-MFMA GEMM)" if args.fp8 else
+                       "dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)"),
+            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
             "flops_per_launch": work / max(n, 1),
-            "gemm_ms_per_image": round(ms / args.steps / B, 2),
-            "attention": {"achieved": round(stats["attention"][1] / max(stats["attention"][0], 1e-9) / 1e9, 1),
-                          "ms_per_image": round(stats["attention"][0] / args.steps / B, 2), "launches": stats["attention"][2]},
-            "conv": {"achieved": round(stats["conv"][1] / max(stats["conv"][0], 1e-9) / 1e9, 1),
-                     "ms_per_image": round(stats["conv"][0] / args.steps / B, 2), "launches": stats["conv"][2]},
-            "instrumented_ms_per_step": round(instr / args.steps * 1e3, 2),
+            "gemm_ms_per_image": round(ms / n_replay / B, 2),
+            "attention": sub("attention"), "conv": sub("conv"),
+            "replayed_images": n_replay * B,
+            "instrumented_ms_per_step": round(instr / n_replay * 1e3, 2),
             "method": "HIP events around every launch on the launch stream, replay of the timed region",
         }
+        if args.fp8:
+            roofline["bf16_gemm"] = sub("gemm")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
-        cpu = cpu_baseline(cfg, S_t, S_i, num_steps, image_flops, step_flops)
+        cpu = cpu_baseline(image_flops)
 
     if rank == 0:
         value = world * args.steps * B / elapsed
         ms_per_step = elapsed / args.steps * 1e3
+        names = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-dev-1024": "FLUX.1-dev 1024x1024 50-step",
+                 "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "tiny": "tiny"}
+        peak_whole = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
         out = {
-            "metric": "images/sec (whole node) FLUX.1-schnell 1024x1024 4-step" if args.workload == "flux-schnell-1024"
-                      else f"images/sec (whole node) {args.workload}",
+            "metric": f"images/sec (whole node) {names[args.workload]}",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
+            "dtype": "fp8 e4m3 weights x MX-fp8 activations (fp32 accumulate), bf16 elsewhere" if args.fp8 else "bf16",
+            "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
             "config": {"workload": f"{args.workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
-                                   f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8",
+                                   f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8"
+                                   + (", guidance embedding on" if cfg.guidance_embed else ""),
                        "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
             "denoise_ms_per_step": round(float(np.mean(denoise_ms)) / num_steps, 2),
             "vae_decode_ms": round(float(np.mean(vae_ms)), 2),
             "algorithmic_tflop_per_image": round(image_flops / 1e12, 2),
-            "mfma_roofline_frac_whole_path": round(image_flops * args.steps * B / elapsed / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "mfma_roofline_frac_whole_path": round(image_flops * args.steps * B / elapsed / (peak_whole * 1e12), 4),
             "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -54,6 +54,22 @@ class dk_mmdit_config(C.Structure):
         ("pooled_text_embed_dim", C.c_int32), ("token_level_text_embed_dim", C.c_int32),
         ("frequency_embed_dim", C.c_int32), ("max_period", C.c_int32),
         ("embed_dtype", C.c_int32), ("layer_norm_eps", C.c_float),
+        ("guidance_embed", C.c_int32), ("fp8_linears", C.c_int32),
+    ]
+
+
+class dk_gemm_fp8_desc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A_scales", C.c_void_p), ("W", C.c_void_p), ("w_scale", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("gate", C.c_void_p), ("res", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+        ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int32), ("a_row0", C.c_int32), ("a_rows", C.c_int32),
+        ("c_seg_len", C.c_int32), ("c_seg_stride", C.c_int32),
+        ("r_seg_len", C.c_int32), ("r_seg_stride", C.c_int32),
+        ("gate_seg_len", C.c_int32), ("gate_stride", C.c_int32),
+        ("epilogue", C.c_int32), ("c_mx8", C.c_int32),
+        ("C_scales", C.c_void_p), ("c_rows", C.c_int32), ("c_row0", C.c_int32), ("c_col0", C.c_int32),
     ]
 
 
@@ -84,6 +100,12 @@ SIGNATURES = {
     "dk_t5_rmsnorm_bf16": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _vp]),
     "dk_text_elementwise": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "dk_t5_bias_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "dk_gemm_fp8": (_i32, [C.POINTER(dk_gemm_fp8_desc), _vp]),
+    "dk_mx_scale_bytes": (_sz, [_i64, _i32]),
+    "dk_quantize_mx8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _vp]),
+    "dk_ln_modulate_mx8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "dk_weight_pitch_fp8": (_i32, [_i32]),
+    "dk_mmdit_set_guidance": (_i32, [_vp, _f32]),
     "dk_ln_modulate_bf16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dk_qk_norm_rope_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "dk_rope_table_f32": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i32), _i32, _f32, _vp]),
@@ -140,7 +162,7 @@ def load() -> C.CDLL:
             raise DkHipError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dk_abi_version() != 1:
+    if lib.dk_abi_version() != 2:
         raise DkHipError("libdk_hip.so ABI version mismatch")
     _lib = lib
     return lib

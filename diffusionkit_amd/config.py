@@ -3,9 +3,12 @@
 Mirrors the fields of the reference's ``MMDiTConfig`` / ``VAEDecoderConfig``
 (reference: python/src/diffusionkit/mlx/config.py:19-71, 74-111, 126-132) that the
 hot path reads.  Fields the reference declares but never reads
-(``upcast_*_blocks``, ``low_memory_mode``) are dropped; ``guidance_embed`` is kept
-only so that FLUX.1-dev can state "absent", as in the reference
-(model_io.py:109,756 selects FLUX_SCHNELL for dev).
+(``upcast_*_blocks``, ``low_memory_mode``) are dropped.  ``guidance_embed`` is the reference's field
+(config.py:71,109): its FLUX_DEV preset sets it, but model_io.py:109,756 selects FLUX_SCHNELL for the
+FLUX.1-dev checkpoint (quirk Q7) and the one call site (mmdit.py:219-220) cannot run; MODEL_CONFIG keeps that
+default, and ``FLUX_DEV`` below enables the published FLUX.1-dev conditioning for callers who pass it.
+``weight_dtype`` has no reference counterpart: "fp8_e4m3" runs the block Linears on the fp8 MFMA
+(BASELINE.json configs[3]).
 """
 from __future__ import annotations
 
@@ -43,6 +46,9 @@ class MMDiTConfig:
     # dtype the timestep embedding is evaluated in (reference config.dtype, quirk Q2)
     dtype: str = "bfloat16"
     guidance_embed: bool = False
+    # storage / MFMA dtype of the transformer blocks' Linear weights: "bfloat16", or "fp8_e4m3" (per-output-channel scales,
+    # MX-fp8 activations quantised on the fly; FLUX geometry only: head_dim 128, token counts multiples of 128)
+    weight_dtype: str = "bfloat16"
 
     @property
     def hidden_size(self) -> int:
@@ -105,6 +111,10 @@ FLUX_SCHNELL = MMDiTConfig(
     use_qk_norm=True,
     dtype="bfloat16",
 )
+
+
+# reference config.py:97-111 (declared there, never selected: quirk Q7)
+FLUX_DEV = replace(FLUX_SCHNELL, guidance_embed=True)
 
 
 def tiny_flux(depth_multimodal: int = 2, depth_unified: int = 2, heads: int = 2,

@@ -78,3 +78,37 @@ void dk_set_error(const std::string& msg);
       return -1;                                                                        \
     }                                                                                   \
   } while (0)
+
+// ---- MX-fp8 activations (OCP e4m3 elements, one E8M0 scale per row and 32 consecutive columns) -----------------------
+// Position of the scale byte of (physical row r, 32-column block kb) in the side array of an activation buffer with
+// n_blk128 = ceil(rows / 128) + 1 row blocks: [kb / 4][r / 128][kb % 4][r % 16][(r / 16) % 8].  The fp8 GEMM
+// (gemm256f8.hip) reads, per wave and 128-column K-tile, the 512 contiguous bytes of its 128-row block: lane
+// (kb % 4) * 16 + r % 16 gets the 8 bytes of its eight 16-row fragments.
+__host__ __device__ __forceinline__ size_t dk_mx_scale_index(unsigned r, unsigned kb, unsigned n_blk128) {
+  return ((((size_t)(kb >> 2) * n_blk128 + (r >> 7)) * 64 + (kb & 3) * 16 + (r & 15)) << 3) + ((r >> 4) & 7);
+}
+// Quantise the 8 values this lane holds of a 32-element block shared by 4 ADJACENT lanes (lane & ~3 .. + 3): returns the 8
+// e4m3 bytes (element 0 in the low byte of .x) and the block's E8M0 scale byte.  Scale = the smallest power of two s with
+// amax / s <= 448 (e4m3's largest finite value), clamped to [2^-126, 2^127]; elements = RNE(v / s), clamped to +-448
+// (the oracle restates exactly this: oracle/fp8.py).
+__device__ __forceinline__ uint2 dk_mx8_quantize8(const float* v, unsigned& e8m0) {
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  const float t = amax * (1.0f / 448.0f);
+  unsigned e = (__float_as_uint(t) + 0x7FFFFFu) >> 23;  // ceil(log2 t) + 127
+  e = e < 1u ? 1u : (e > 254u ? 254u : e);
+  const float inv = __uint_as_float((254u - e) << 23);  // 2^(127 - e)
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = __builtin_amdgcn_fmed3f(v[i] * inv, -448.0f, 448.0f);
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(s[4], s[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(s[6], s[7], w1, true);
+  e8m0 = e;
+  return make_uint2((unsigned)w0, (unsigned)w1);
+}

@@ -59,7 +59,54 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles
 // back to two launches when the pair is not eligible for the grouped kernel
 int dk_launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t stream);
 
-// optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention
+// ---- fp8 GEMM (gemm256f8.hip): e4m3 weights with per-output-channel fp32 scales, MX-fp8 activations -------------------
+// C[m, n] = epi(wscale[n] * sum_k A[m, k] * 2^(SA[m, k / 32] - 127) * W[n, k] + bias[n]); same row-segment maps, epilogues,
+// grouped launch and column split as GemmParams.  Strides of A / W and of an MX-fp8 output are in BYTES (= elements).
+struct GemmF8Params {
+  const unsigned char* A;   // [rows, K] e4m3, row pitch lda
+  const unsigned char* SA;  // E8M0 scales of the A BUFFER (dk_mx_scale_index over its physical rows), sa_nblk 128-row blocks per K-tile
+  const unsigned char* W;   // [N, K] e4m3, row pitch ldw
+  const float* wscale;      // [N]
+  void* C;                  // bf16 [., ldc] or, with c_mx8, e4m3 [., ldc] + scales into SC
+  const bf16_t* bias;
+  const bf16_t* gate;
+  const bf16_t* res;
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int a_seg_len, a_seg_stride, a_row0;  // a_row0: physical row of the A buffer that pointer A addresses (scale indexing)
+  int sa_nblk;
+  int c_seg_len, c_seg_stride;
+  int r_seg_len, r_seg_stride;
+  int gate_seg_len, gate_stride;
+  int epi;
+  int c_mx8;
+  // optional column split: output columns >= n_split go to C2 (column index rebased to 0) with epilogue epi2
+  int n_split;
+  void* C2;
+  int ldc2, epi2, c2_mx8;
+  // MX-fp8 outputs: scale side array of the OUTPUT buffer, its 128-row block count, the physical row that pointer C / C2
+  // addresses, and the 32-column block index of output column 0 inside that buffer's rows
+  unsigned char* SC;
+  int sc_nblk, c_row0, sc_kb0;
+};
+bool dk_gemm256f8_eligible(const GemmF8Params& p);
+int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream_t stream);
+// bf16 rows -> MX-fp8 rows + scales (fp8_ops.hip).  x: [M, h] bf16 through the row map (seg_len, seg_stride); out row m at
+// physical row out_row0 + (m / o_seg_len) * o_seg_stride + m % o_seg_len of the fp8 buffer (pitch ldo bytes, column
+// offset col0, a multiple of 32).  dk_launch_ln_modulate_mx8 = dk_launch_ln_modulate with that output.
+struct Mx8Out {
+  unsigned char* out;  // buffer base (physical row 0, column 0)
+  unsigned char* scales;
+  int ldo, n_blk128, row0, seg_len, seg_stride, col0;
+};
+int dk_launch_quantize_mx8(const bf16_t* x, int ldx, int x_seg_len, int x_seg_stride, int M, int h, const Mx8Out& o, hipStream_t stream);
+int dk_launch_ln_modulate_mx8(const bf16_t* x, int ldx, int M, int h, const bf16_t* shift, const bf16_t* scale, int mod_stride, int seg_len,
+                              int x_seg_len, int x_seg_stride, float eps, const Mx8Out& o, hipStream_t stream);
+int dk_launch_ln_modulate2_mx8(const bf16_t* x0, int M0, const bf16_t* shift0, const bf16_t* scale0, int seg0, const Mx8Out& o0,
+                               const bf16_t* x1, int M1, const bf16_t* shift1, const bf16_t* scale1, int seg1, const Mx8Out& o1, int ldx, int h,
+                               int mod_stride, int x_seg_stride, float eps, hipStream_t stream);
+
+// optional HIP-event timing of the dominant kernels (profile.hip); cls: 0 GEMM, 1 conv, 2 attention, 3 fp8 GEMM
 void dk_prof_begin(int cls, double work, hipStream_t st);
 void dk_prof_end(hipStream_t st);
 

@@ -132,6 +132,49 @@ extern "C" int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_
                                eps, S_(stream));
 }
 
+extern "C" int32_t dk_weight_pitch_fp8(int32_t k) { return k >= g_dk_pitch_min_k ? k + 128 : k; }
+static int mx_nblk(long rows) { return (int)((rows + 127) / 128 + 1); }
+extern "C" size_t dk_mx_scale_bytes(int64_t rows, int32_t k) { return (size_t)((k + 127) / 128) * (size_t)mx_nblk((long)rows) * 512; }
+
+extern "C" int dk_gemm_fp8(const dk_gemm_fp8_desc* d, void* stream) {
+  DK_REQUIRE(d != nullptr, "null descriptor");
+  GemmF8Params p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const unsigned char*)d->A; p.SA = (const unsigned char*)d->A_scales; p.W = (const unsigned char*)d->W; p.wscale = d->w_scale;
+  p.C = d->C; p.bias = (const bf16_t*)d->bias; p.gate = (const bf16_t*)d->gate; p.res = (const bf16_t*)d->res;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.a_seg_len = d->a_seg_len > 0 ? d->a_seg_len : (d->M + 127) / 128 * 128; p.a_seg_stride = d->a_seg_stride; p.a_row0 = d->a_row0;
+  p.sa_nblk = mx_nblk(d->a_rows);
+  p.c_seg_len = d->c_seg_len > 0 ? d->c_seg_len : d->M; p.c_seg_stride = d->c_seg_stride;
+  p.r_seg_len = d->r_seg_len > 0 ? d->r_seg_len : d->M; p.r_seg_stride = d->r_seg_stride;
+  p.gate_seg_len = d->gate_seg_len > 0 ? d->gate_seg_len : d->M; p.gate_stride = d->gate_stride;
+  p.epi = d->epilogue; p.c_mx8 = d->c_mx8;
+  if (d->c_mx8) {
+    DK_REQUIRE(d->M % 256 == 0 && d->c_col0 % 32 == 0 && d->C_scales != nullptr, "MX-fp8 output: M a multiple of 256, column offset a multiple of 32");
+    p.SC = (unsigned char*)d->C_scales; p.sc_nblk = mx_nblk(d->c_rows); p.c_row0 = d->c_row0; p.sc_kb0 = d->c_col0 / 32;
+  }
+  return dk_launch_gemm256f8(p, nullptr, S_(stream));
+}
+static Mx8Out mx8_out(void* out, void* scales, int ldo, long rows, int row0, int seg_len, int seg_stride, int col0) {
+  Mx8Out o;
+  o.out = (unsigned char*)out; o.scales = (unsigned char*)scales; o.ldo = ldo; o.n_blk128 = mx_nblk(rows); o.row0 = row0;
+  o.seg_len = seg_len; o.seg_stride = seg_stride; o.col0 = col0;
+  return o;
+}
+extern "C" int dk_quantize_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, void* out, int32_t ldo, void* out_scales, int64_t out_rows,
+                               int32_t out_row0, int32_t out_col0, void* stream) {
+  DK_REQUIRE(x && out && out_scales && M > 0, "bad argument");
+  return dk_launch_quantize_mx8((const bf16_t*)x, ldx, M, 0, M, h, mx8_out(out, out_scales, ldo, (long)out_rows, out_row0, M, 0, out_col0), S_(stream));
+}
+extern "C" int dk_ln_modulate_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, const void* shift, const void* scale, int32_t mod_stride,
+                                  int32_t mod_seg_len, float eps, void* out, int32_t ldo, void* out_scales, int64_t out_rows,
+                                  int32_t out_row0, void* stream) {
+  DK_REQUIRE(x && out && out_scales && M > 0, "bad argument");
+  return dk_launch_ln_modulate_mx8((const bf16_t*)x, ldx, M, h, (const bf16_t*)shift, (const bf16_t*)scale, mod_stride,
+                                   mod_seg_len > 0 ? mod_seg_len : M, M, 0, eps, mx8_out(out, out_scales, ldo, (long)out_rows, out_row0, M, 0, 0),
+                                   S_(stream));
+}
+
 extern "C" int dk_qk_norm_rope_bf16(void* qkv, int32_t ld, int32_t q_off, int32_t k_off, int32_t rows, int32_t H, int32_t D,
                                     const void* q_weight, const void* k_weight, float eps, const float* rope_table,
                                     int32_t row_seg_len, int32_t row_seg_stride, int32_t pos_off, void* stream) {
@@ -265,6 +308,9 @@ struct StreamW {  // one TransformerBlock's weights (mmdit.py:395-438)
   const bf16_t *qkv_w = nullptr, *qkv_b = nullptr, *qn = nullptr, *kn = nullptr;
   const bf16_t *o_w = nullptr, *o_b = nullptr, *fc1_w = nullptr, *fc1_b = nullptr, *fc2_w = nullptr, *fc2_b = nullptr;
   const bf16_t *l2_w = nullptr, *l2_b = nullptr;  // single blocks: [h, 5h] = [o_proj | fc2]
+  // fp8_linears: e4m3 weights + per-output-channel scales instead of the bf16 matrices above (biases stay bf16)
+  const unsigned char *qkv_w8 = nullptr, *o_w8 = nullptr, *fc1_w8 = nullptr, *fc2_w8 = nullptr, *l2_w8 = nullptr;
+  const float *qkv_ws = nullptr, *o_ws = nullptr, *fc1_ws = nullptr, *fc2_ws = nullptr, *l2_ws = nullptr;
 };
 
 struct dk_mmdit {
@@ -286,6 +332,15 @@ struct dk_mmdit {
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_streamk_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
+  // guidance embedding (cfg.guidance_embed): MLPEmbedder weights, the value set by dk_mmdit_set_guidance, scratch rows
+  const bf16_t *g0_w = nullptr, *g0_b = nullptr, *g2_w = nullptr, *g2_b = nullptr;
+  float guidance = 3.5f;
+  bf16_t *gemb = nullptr, *g1 = nullptr, *gvec = nullptr;
+  // fp8_linears: MX-fp8 activation buffers + their scale side arrays (layout dk_mx_scale_index)
+  unsigned char *XN8 = nullptr, *ATT8 = nullptr, *HC8 = nullptr;    // [BS, h], [BS, h], max([BS, ldh8], [BS, ldcat8])
+  unsigned char *SXN = nullptr, *SATT = nullptr, *SHID = nullptr, *SCAT = nullptr;
+  int ldh8 = 0, ldcat8 = 0, nblk = 0;
+  bool fp8() const { return cfg.fp8_linears != 0; }
 
   int h() const { return cfg.hidden_size; }
   int D() const { return cfg.hidden_size / cfg.num_heads; }
@@ -328,9 +383,17 @@ extern "C" int dk_mmdit_create(const dk_mmdit_config* cfg, dk_mmdit** out) {
     for (int i = 0; i < cfg->n_rope_axes; ++i) half += cfg->rope_axes_dim[i] / 2;
     DK_REQUIRE(half * 2 == D, "rope axes must sum to head_dim");
   }
+  if (cfg->fp8_linears) DK_REQUIRE(D == 128 && cfg->hidden_size % 256 == 0, "fp8_linears: head_dim 128 and hidden_size a multiple of 256");
   dk_mmdit* m = new dk_mmdit();
   m->cfg = *cfg;
   *out = m;
+  return 0;
+}
+extern "C" int dk_mmdit_set_guidance(dk_mmdit* m, float guidance) {
+  DK_REQUIRE(m != nullptr, "null handle");
+  DK_REQUIRE(m->cfg.guidance_embed, "this configuration has no guidance embedding (guidance_embed = 0)");
+  m->guidance = guidance;
+  m->mod_ready = false;
   return 0;
 }
 extern "C" void dk_mmdit_destroy(dk_mmdit* m) { delete m; }
@@ -357,15 +420,25 @@ static int need(const std::unordered_map<std::string, const void*>& named, const
   return 0;
 }
 
+// the matrix of one Linear: bf16 "<name>.weight", or (fp8_linears) e4m3 "<name>.weight_fp8" + f32 "<name>.wscale"
+static int need_matrix(dk_mmdit* m, const std::string& name, const bf16_t** w, const unsigned char** w8, const float** ws) {
+  if (!m->fp8()) return need(m->named, name + ".weight", w);
+  const bf16_t *a = nullptr, *b = nullptr;
+  DK_TRY(need(m->named, name + ".weight_fp8", &a));
+  DK_TRY(need(m->named, name + ".wscale", &b));
+  *w8 = (const unsigned char*)a;
+  *ws = (const float*)b;
+  return 0;
+}
 static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool single, bool skip_post) {
   const auto& n = m->named;
   if (single) {  // fused [q|k|v|fc1] matrix; fc1 views point into it
-    DK_TRY(need(n, p + ".linear1.weight", &w.qkv_w));
+    DK_TRY(need_matrix(m, p + ".linear1", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
     DK_TRY(need(n, p + ".linear1.bias", &w.qkv_b));
-    w.fc1_w = w.qkv_w + (size_t)3 * m->h() * m->h();
+    if (!m->fp8()) w.fc1_w = w.qkv_w + (size_t)3 * m->h() * m->h();
     w.fc1_b = w.qkv_b + 3 * m->h();
   } else {
-    DK_TRY(need(n, p + ".attn.qkv.weight", &w.qkv_w));
+    DK_TRY(need_matrix(m, p + ".attn.qkv", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
     DK_TRY(need(n, p + ".attn.qkv.bias", &w.qkv_b));
   }
   if (m->cfg.use_qk_norm) {
@@ -374,16 +447,16 @@ static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool si
   }
   if (skip_post) return 0;
   if (!single) {
-    DK_TRY(need(n, p + ".mlp.fc1.weight", &w.fc1_w));
+    DK_TRY(need_matrix(m, p + ".mlp.fc1", &w.fc1_w, &w.fc1_w8, &w.fc1_ws));
     DK_TRY(need(n, p + ".mlp.fc1.bias", &w.fc1_b));
   }
   if (single) {
-    DK_TRY(need(n, p + ".linear2.weight", &w.l2_w));
+    DK_TRY(need_matrix(m, p + ".linear2", &w.l2_w, &w.l2_w8, &w.l2_ws));
     DK_TRY(need(n, p + ".linear2.bias", &w.l2_b));
   } else {
-    DK_TRY(need(n, p + ".attn.o_proj.weight", &w.o_w));
+    DK_TRY(need_matrix(m, p + ".attn.o_proj", &w.o_w, &w.o_w8, &w.o_ws));
     DK_TRY(need(n, p + ".attn.o_proj.bias", &w.o_b));
-    DK_TRY(need(n, p + ".mlp.fc2.weight", &w.fc2_w));
+    DK_TRY(need_matrix(m, p + ".mlp.fc2", &w.fc2_w, &w.fc2_w8, &w.fc2_ws));
     DK_TRY(need(n, p + ".mlp.fc2.bias", &w.fc2_b));
   }
   return 0;
@@ -409,6 +482,12 @@ static int mmdit_resolve(dk_mmdit* m) {
   DK_TRY(need(n, "adaLN.bias", &m->adaln_b));
   DK_TRY(need(n, "final_layer.linear.weight", &m->final_w));
   DK_TRY(need(n, "final_layer.linear.bias", &m->final_b));
+  if (m->cfg.guidance_embed) {
+    DK_TRY(need(n, "guidance_in.mlp.layers.0.weight", &m->g0_w));
+    DK_TRY(need(n, "guidance_in.mlp.layers.0.bias", &m->g0_b));
+    DK_TRY(need(n, "guidance_in.mlp.layers.2.weight", &m->g2_w));
+    DK_TRY(need(n, "guidance_in.mlp.layers.2.bias", &m->g2_b));
+  }
   m->dimg.assign(m->cfg.depth_multimodal, StreamW());
   m->dtxt.assign(m->cfg.depth_multimodal, StreamW());
   m->single.assign(m->cfg.depth_unified, StreamW());
@@ -435,8 +514,22 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->ldcat = dk_weight_pitch((1 + m->cfg.mlp_ratio) * h);
   const size_t hid = BS * m->ldh * 2;  // MLP hidden of both streams of a double block (image rows first)
   const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)m->ldcat * 2 : 0;
-  m->CAT = (bf16_t*)c.take(cat > hid ? cat : hid);  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
+  m->CAT = (bf16_t*)c.take(m->fp8() ? 0 : (cat > hid ? cat : hid));  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
   m->HID = m->CAT;
+  if (m->fp8()) {  // the same buffers in MX-fp8 (the bf16 X, QKV, ATT above stay: residual stream, attention operands / output)
+    const int r = m->cfg.mlp_ratio;
+    m->ldh8 = dk_weight_pitch_fp8(r * h);
+    m->ldcat8 = dk_weight_pitch_fp8((1 + r) * h);
+    m->nblk = mx_nblk((long)BS);
+    m->XN8 = (unsigned char*)c.take(BS * h);
+    m->ATT8 = (unsigned char*)c.take(BS * h);
+    const size_t hid8 = BS * (size_t)m->ldh8, cat8 = m->cfg.depth_unified > 0 ? BS * (size_t)m->ldcat8 : 0;
+    m->HC8 = (unsigned char*)c.take(cat8 > hid8 ? cat8 : hid8);
+    m->SXN = (unsigned char*)c.take(dk_mx_scale_bytes((long)BS, h));
+    m->SATT = (unsigned char*)c.take(dk_mx_scale_bytes((long)BS, h));
+    m->SHID = (unsigned char*)c.take(dk_mx_scale_bytes((long)BS, r * h));
+    m->SCAT = (unsigned char*)c.take(m->cfg.depth_unified > 0 ? dk_mx_scale_bytes((long)BS, (1 + r) * h) : 0);
+  }
   m->MOD = (bf16_t*)c.take((size_t)n_t * B * m->mod_rows() * h * 2);
   m->POS = (bf16_t*)c.take(m->cfg.use_pos_embed ? (size_t)S_i * h * 2 : 0);
   m->CTXE = (bf16_t*)c.take((size_t)B * S_t * h * 2);
@@ -446,6 +539,9 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->y1 = (bf16_t*)c.take((size_t)B * h * 2);
   m->yvec = (bf16_t*)c.take((size_t)B * h * 2);
   m->vec = (bf16_t*)c.take((size_t)n_t * B * h * 2);
+  m->gemb = (bf16_t*)c.take(m->cfg.guidance_embed ? (size_t)m->cfg.frequency_embed_dim * 2 : 0);
+  m->g1 = (bf16_t*)c.take(m->cfg.guidance_embed ? (size_t)h * 2 : 0);
+  m->gvec = (bf16_t*)c.take(m->cfg.guidance_embed ? (size_t)h * 2 : 0);
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
   m->GWS = c.take(dk_streamk_workspace_bytes());
@@ -466,6 +562,11 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   const int p = m->cfg.patch_size;
   DK_REQUIRE(latent_h % p == 0 && latent_w % p == 0, "latent size must be divisible by the patch size");
   DK_TRY(mmdit_resolve(m));
+  if (m->fp8()) {
+    const int S_i_ = (latent_h / p) * (latent_w / p);
+    DK_REQUIRE(text_len % 128 == 0 && S_i_ % 128 == 0,
+               "fp8_linears: text_len and the number of image tokens must be multiples of 128 (MX scale blocks of 128 rows)");
+  }
   DK_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   Carver c(workspace, workspace_bytes);
   const size_t need_bytes = mmdit_carve(m, c, batch, latent_h, latent_w, text_len, n_timesteps);
@@ -493,6 +594,7 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   return 0;
 }
 
+static bool c_guidance(const dk_mmdit* m) { return m->cfg.guidance_embed != 0; }
 extern "C" int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled, const float* timesteps_host, int32_t n,
                                                 void* stream) {
   DK_REQUIRE(m && m->prepared, "dk_mmdit_prepare must be called first");
@@ -506,6 +608,16 @@ extern "C" int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled,
   DK_TRY(linear_plain(m->t1, m->t2_w, m->t2_b, m->tvec, n, h, h, DK_EPI_BIAS, st));
   DK_TRY(linear_plain((const bf16_t*)pooled, m->y0_w, m->y0_b, m->y1, B, h, P, DK_EPI_BIAS_SILU, st));
   DK_TRY(linear_plain(m->y1, m->y2_w, m->y2_b, m->yvec, B, h, h, DK_EPI_BIAS, st));
+  if (c_guidance(m)) {
+    // FLUX.1-dev guidance embedding (MLPEmbedder, mmdit.py:31-36,945-955): g = guidance_in(timestep_embedding(1000 * guidance)),
+    // added to the pooled-text embedding of every batch row, hence to every modulation vector
+    const float gt = 1000.0f * m->guidance;
+    DK_CHECK_HIP(hipMemcpyAsync(m->tdev, &gt, 4, hipMemcpyHostToDevice, st));  // (tdev[0] was consumed by the launch above, same stream)
+    DK_TRY(dk_launch_timestep_embedding(m->tdev, 1, 1, Fq, (float)m->cfg.max_period, m->cfg.embed_dtype, m->gemb, st));
+    DK_TRY(linear_plain(m->gemb, m->g0_w, m->g0_b, m->g1, 1, h, Fq, DK_EPI_BIAS_SILU, st));
+    DK_TRY(linear_plain(m->g1, m->g2_w, m->g2_b, m->gvec, 1, h, h, DK_EPI_BIAS, st));
+    DK_TRY(dk_launch_add(m->yvec, m->gvec, 1, m->yvec, B, h, st));  // y[b] += g
+  }
   // vec[step*B + b] = silu(y[b] + t[step]); adaLN_modulation = SiLU -> Linear (mmdit.py:94-96,430-435)
   DK_TRY(dk_launch_add(m->yvec, m->tvec, n, m->vec, n * B, h, st));
   DK_TRY(dk_launch_silu(m->vec, m->vec, (long)n * B * h, st));
@@ -552,6 +664,152 @@ extern "C" int dk_mmdit_cache_context(dk_mmdit* m, const void* text, void* strea
   return 0;
 }
 
+// FinalLayer (mmdit.py:767-796) on the image rows
+static int mmdit_final_layer(dk_mmdit* m, const bf16_t* mod_step, bf16_t* tokens_out, hipStream_t st) {
+  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F();
+  const int mod_stride = m->mod_rows() * h;
+  const bf16_t* mod_fin = mod_step + (size_t)m->mod_offset(3, 0) * h;
+  DK_TRY(dk_launch_ln_modulate(m->X + (size_t)S_t * h, h, m->XN, h, B * S_i, h, mod_fin, mod_fin + h, mod_stride, S_i, S_i, S,
+                               m->cfg.layer_norm_eps, st));
+  return linear_plain(m->XN, m->final_w, m->final_b, tokens_out, B * S_i, F, h, DK_EPI_BIAS, st);
+}
+
+// ---- fp8_linears: the transformer blocks on the fp8 GEMM (gemm256f8.hip) -------------------------------------------------
+// A Linear over MX-fp8 activations.  abuf / sa: the fp8 activation buffer and its scale side array (pitch lda bytes); the GEMM
+// reads logical rows through (a_row0, a_seg_len, a_seg_stride) -- all multiples of 128 rows (checked in dk_mmdit_prepare).
+static GemmF8Params f8_params(const dk_mmdit* m, const unsigned char* abuf, const unsigned char* sa, int lda, int a_row0, int a_seg_len,
+                              int a_seg_stride, const unsigned char* W, int ldw, const float* ws, const bf16_t* bias, int M, int N, int K,
+                              int epi) {
+  GemmF8Params p;
+  memset(&p, 0, sizeof(p));
+  p.A = abuf + (size_t)a_row0 * lda; p.SA = sa; p.W = W; p.wscale = ws; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+  p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride; p.a_row0 = a_row0; p.sa_nblk = m->nblk;
+  p.epi = epi;
+  return p;
+}
+static void f8_out_bf16(GemmF8Params& p, bf16_t* C, int ldc, int c_seg_len, int c_seg_stride) {
+  p.C = C; p.ldc = ldc; p.c_seg_len = c_seg_len; p.c_seg_stride = c_seg_stride; p.c_mx8 = 0;
+  p.r_seg_len = p.M; p.gate_seg_len = p.M;
+}
+static void f8_gate_res(GemmF8Params& p, const bf16_t* gate, int gate_seg_len, int gate_stride, const bf16_t* res, int ldr, int r_seg_len,
+                        int r_seg_stride) {
+  p.gate = gate; p.gate_seg_len = gate_seg_len; p.gate_stride = gate_stride; p.res = res; p.ldr = ldr; p.r_seg_len = r_seg_len;
+  p.r_seg_stride = r_seg_stride;
+}
+static int f8_pair(const GemmF8Params& a, const GemmF8Params* b, hipStream_t st) { return dk_launch_gemm256f8(a, b, st); }
+
+static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st) {
+  const dk_mmdit_config& c = m->cfg;
+  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, r = c.mlp_ratio;
+  const int mod_stride = m->mod_rows() * h;
+  const float scale = 1.0f / sqrtf((float)m->D());
+  bf16_t* X_img = m->X + (size_t)S_t * h;
+  bf16_t* X_txt = m->X;
+  const int Mi = B * S_i, Mt = B * S_t;
+  const long BS = (long)B * S;
+  const int ldh8 = m->ldh8, ldcat8 = m->ldcat8;
+  // XN8 / HID8 keep the bf16 path's row order: image rows [0, Mi), text rows [Mi, Mi + Mt); ATT8 / CAT8 are indexed like the
+  // joint stream (b * S + s)
+  const Mx8Out xn_img = mx8_out(m->XN8, m->SXN, h, BS, 0, Mi, 0, 0), xn_txt = mx8_out(m->XN8, m->SXN, h, BS, Mi, Mt, 0, 0);
+  for (int i = 0; i < c.depth_multimodal; ++i) {
+    const bf16_t* mod_img = mod_step + (size_t)m->mod_offset(0, i) * h;
+    const bf16_t* mod_txt = mod_step + (size_t)m->mod_offset(1, i) * h;
+    const StreamW& wi = m->dimg[i];
+    const StreamW& wt = m->dtxt[i];
+    const bool txt_post = !m->txt_skipped(i);
+    // pre_sdpa (mmdit.py:440-519): LN-modulate -> MX-fp8, q/k/v projection, QK-norm (+ RoPE)
+    DK_TRY(dk_launch_ln_modulate2_mx8(X_img, Mi, mod_img, mod_img + h, S_i, xn_img, X_txt, Mt, mod_txt, mod_txt + h, S_t, xn_txt, h, h, mod_stride,
+                                      S, c.layer_norm_eps, st));
+    {
+      GemmF8Params qi = f8_params(m, m->XN8, m->SXN, h, 0, Mi, 0, wi.qkv_w8, h, wi.qkv_ws, wi.qkv_b, Mi, 3 * h, h, DK_EPI_BIAS);
+      GemmF8Params qt = f8_params(m, m->XN8, m->SXN, h, Mi, Mt, 0, wt.qkv_w8, h, wt.qkv_ws, wt.qkv_b, Mt, 3 * h, h, DK_EPI_BIAS);
+      f8_out_bf16(qi, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S);
+      f8_out_bf16(qt, m->QKV, 3 * h, S_t, S);
+      DK_TRY(f8_pair(qi, &qt, st));
+    }
+    DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
+                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
+    AttnParams ap;
+    ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
+    ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
+    if (fuse_q()) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    DK_TRY(dk_launch_attention(ap, st));
+    DK_TRY(dk_launch_quantize_mx8(m->ATT, h, (int)BS, 0, (int)BS, h, mx8_out(m->ATT8, m->SATT, h, BS, 0, (int)BS, 0, 0), st));
+    // post_sdpa (mmdit.py:537-548): residual += gate_attn * o_proj(attn)
+    {
+      GemmF8Params oi = f8_params(m, m->ATT8, m->SATT, h, S_t, S_i, S, wi.o_w8, h, wi.o_ws, wi.o_b, Mi, h, h, DK_EPI_GATE_RES);
+      f8_out_bf16(oi, X_img, h, S_i, S);
+      f8_gate_res(oi, mod_img + 2 * h, S_i, mod_stride, X_img, h, S_i, S);
+      if (txt_post) {
+        GemmF8Params ot = f8_params(m, m->ATT8, m->SATT, h, 0, S_t, S, wt.o_w8, h, wt.o_ws, wt.o_b, Mt, h, h, DK_EPI_GATE_RES);
+        f8_out_bf16(ot, X_txt, h, S_t, S);
+        f8_gate_res(ot, mod_txt + 2 * h, S_t, mod_stride, X_txt, h, S_t, S);
+        DK_TRY(f8_pair(oi, &ot, st));
+      } else {
+        DK_TRY(f8_pair(oi, nullptr, st));
+      }
+    }
+    // residual += gate_mlp * fc2(gelu(fc1(LN-mod(residual)))); the MLP hidden leaves fc1 as MX-fp8
+    if (txt_post)
+      DK_TRY(dk_launch_ln_modulate2_mx8(X_img, Mi, mod_img + 3 * h, mod_img + 4 * h, S_i, xn_img, X_txt, Mt, mod_txt + 3 * h, mod_txt + 4 * h, S_t,
+                                        xn_txt, h, h, mod_stride, S, c.layer_norm_eps, st));
+    else
+      DK_TRY(dk_launch_ln_modulate_mx8(X_img, h, Mi, h, mod_img + 3 * h, mod_img + 4 * h, mod_stride, S_i, S_i, S, c.layer_norm_eps, xn_img, st));
+    {
+      GemmF8Params f1i = f8_params(m, m->XN8, m->SXN, h, 0, Mi, 0, wi.fc1_w8, h, wi.fc1_ws, wi.fc1_b, Mi, r * h, h, DK_EPI_BIAS_GELU);
+      f1i.C = m->HC8; f1i.ldc = ldh8; f1i.c_seg_len = Mi; f1i.c_mx8 = 1; f1i.SC = m->SHID; f1i.sc_nblk = m->nblk; f1i.c_row0 = 0; f1i.sc_kb0 = 0;
+      f1i.r_seg_len = Mi; f1i.gate_seg_len = Mi;
+      GemmF8Params f2i = f8_params(m, m->HC8, m->SHID, ldh8, 0, Mi, 0, wi.fc2_w8, ldh8, wi.fc2_ws, wi.fc2_b, Mi, h, r * h, DK_EPI_GATE_RES);
+      f8_out_bf16(f2i, X_img, h, S_i, S);
+      f8_gate_res(f2i, mod_img + 5 * h, S_i, mod_stride, X_img, h, S_i, S);
+      if (txt_post) {
+        GemmF8Params f1t = f8_params(m, m->XN8, m->SXN, h, Mi, Mt, 0, wt.fc1_w8, h, wt.fc1_ws, wt.fc1_b, Mt, r * h, h, DK_EPI_BIAS_GELU);
+        f1t.C = m->HC8 + (size_t)Mi * ldh8; f1t.ldc = ldh8; f1t.c_seg_len = Mt; f1t.c_mx8 = 1; f1t.SC = m->SHID; f1t.sc_nblk = m->nblk; f1t.c_row0 = Mi;
+        f1t.sc_kb0 = 0; f1t.r_seg_len = Mt; f1t.gate_seg_len = Mt;
+        GemmF8Params f2t = f8_params(m, m->HC8, m->SHID, ldh8, Mi, Mt, 0, wt.fc2_w8, ldh8, wt.fc2_ws, wt.fc2_b, Mt, h, r * h, DK_EPI_GATE_RES);
+        f8_out_bf16(f2t, X_txt, h, S_t, S);
+        f8_gate_res(f2t, mod_txt + 5 * h, S_t, mod_stride, X_txt, h, S_t, S);
+        DK_TRY(f8_pair(f1i, &f1t, st));
+        DK_TRY(f8_pair(f2i, &f2t, st));
+      } else {
+        DK_TRY(f8_pair(f1i, nullptr, st));
+        DK_TRY(f8_pair(f2i, nullptr, st));
+      }
+    }
+  }
+  // UnifiedTransformerBlock x depth_unified (mmdit.py:693-751)
+  const int M = B * S;
+  const Mx8Out xn_all = mx8_out(m->XN8, m->SXN, h, BS, 0, M, 0, 0);
+  for (int i = 0; i < c.depth_unified; ++i) {
+    const StreamW& w = m->single[i];
+    const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
+    DK_TRY(dk_launch_ln_modulate_mx8(m->X, h, M, h, mod, mod + h, mod_stride, S, M, 0, c.layer_norm_eps, xn_all, st));
+    {  // linear1: [q|k|v] -> QKV (bf16), gelu(fc1) -> CAT8[:, h:] (MX-fp8), one pass over the modulated activations
+      GemmF8Params l1 = f8_params(m, m->XN8, m->SXN, h, 0, M, 0, w.qkv_w8, h, w.qkv_ws, w.qkv_b, M, (3 + r) * h, h, DK_EPI_BIAS);
+      f8_out_bf16(l1, m->QKV, 3 * h, M, 0);
+      l1.n_split = 3 * h; l1.C2 = m->HC8 + h; l1.ldc2 = ldcat8; l1.epi2 = DK_EPI_BIAS_GELU; l1.c2_mx8 = 1;
+      l1.SC = m->SCAT; l1.sc_nblk = m->nblk; l1.c_row0 = 0; l1.sc_kb0 = h / 32;
+      DK_TRY(f8_pair(l1, nullptr, st));
+    }
+    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr, S, S, 0, S,
+                                  st, fuse_q()));
+    AttnParams ap;
+    ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
+    ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
+    if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    DK_TRY(dk_launch_attention(ap, st));
+    DK_TRY(dk_launch_quantize_mx8(m->ATT, h, M, 0, M, h, mx8_out(m->HC8, m->SCAT, ldcat8, BS, 0, M, 0, 0), st));
+    {  // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
+      GemmF8Params l2 = f8_params(m, m->HC8, m->SCAT, ldcat8, 0, M, 0, w.l2_w8, ldcat8, w.l2_ws, w.l2_b, M, h, (1 + r) * h, DK_EPI_GATE_RES);
+      f8_out_bf16(l2, m->X, h, M, 0);
+      f8_gate_res(l2, mod + 2 * h, S, mod_stride, m->X, h, M, 0);
+      DK_TRY(f8_pair(l2, nullptr, st));
+    }
+  }
+  return 0;
+}
+
 extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index, void* tokens_out,
                                 void* stream) {
   DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
@@ -578,6 +836,10 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
                      c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
 
+  if (m->fp8()) {
+    DK_TRY(mmdit_blocks_fp8(m, mod_step, st));
+    return mmdit_final_layer(m, mod_step, (bf16_t*)tokens_out, st);
+  }
   // MultiModalTransformerBlock x depth_multimodal (mmdit.py:568-675).  The two streams run the same
   // Linear shapes on different weights; their GEMMs are issued as pairs so that the 256 x 256 kernel can
   // place the text tiles in the same wave as the image tiles (dk_launch_gemm_pair).
@@ -673,12 +935,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
                        m->X, h, M, 0, st, ldcat));
   }
 
-  // FinalLayer (mmdit.py:767-796) on the image rows
-  const bf16_t* mod_fin = mod_step + (size_t)m->mod_offset(3, 0) * h;
-  DK_TRY(dk_launch_ln_modulate(m->X + (size_t)S_t * h, h, m->XN, h, B * S_i, h, mod_fin, mod_fin + h, mod_stride, S_i, S_i, S,
-                               c.layer_norm_eps, st));
-  DK_TRY(linear_plain(m->XN, m->final_w, m->final_b, (bf16_t*)tokens_out, B * S_i, F, h, DK_EPI_BIAS, st));
-  return 0;
+  return mmdit_final_layer(m, mod_step, (bf16_t*)tokens_out, st);
 }
 
 extern "C" const void* dk_mmdit_debug_buffer(const dk_mmdit* m, int32_t which) {

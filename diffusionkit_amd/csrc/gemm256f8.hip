@@ -1,0 +1,469 @@
+// 256 x 256 x 128 fp8 (OCP e4m3) GEMM on the block-scaled MFMA of gfx950: fp8 weights / fp8-quantised activations, fp32
+// accumulation, bf16 (or MX-fp8) output -- the Linear layers of the MMDiT blocks for BASELINE.json configs[3]
+// ("FLUX.1-dev, fp8 weights / bf16 activations, CDNA4 fp8 MFMA").  Call sites: every nn.Linear of the transformer blocks,
+// python/src/diffusionkit/mlx/mmdit.py:821-832 and the fused linear1 / linear2 of the single-stream blocks (:693-751);
+// the reference's own quantised path is MLX's 4-bit nn.QuantizedLinear (mlx/model_io.py:728-734,772-775) -- this is the
+// MI355X-native counterpart, not a restatement of it.
+//
+// Number formats
+//   W   [N, K] e4m3 + one fp32 scale per output channel (wscale[n], applied in the tail); the hardware scale of the
+//       weight operand is the constant 2^0.
+//   A   [M, K] e4m3 + one E8M0 scale per (row, 32 consecutive K) -- the OCP MX block format.  The hardware applies it:
+//       v_mfma_scale_f32_16x16x128_f8f6f4 takes, per lane, the scale of the lane's (row, 32-K block) from a byte of a VGPR.
+//       Scale bytes live in a side array laid out so that ONE coalesced 8-byte load per lane and K-tile brings a wave the
+//       scales of its 128 rows (dk_mx_scale_index below); producers: dk_ln_modulate_mx8, dk_quantize_mx8 (fp8_ops.hip)
+//       and this kernel's own tail (fc1 + GELU -> fc2's input).
+//   C   bf16 like the bf16 kernels, or MX-fp8 (same format as A) when the consumer is another fp8 GEMM.
+//
+// Kernel shape = the bf16 kernel's (gemm256v3.hip): 8 waves (2 x 4), wave tile 128 (m) x 64 (n), LDS-DMA
+// (buffer_load_dwordx4 ... lds) into a 2-deep ring of 64 KiB K-tiles, hand-counted LDS waits, LDS-staged row-major tail.
+// A K-tile is 128 fp8 = 128 bytes per row -- byte-for-byte the bf16 kernel's 64-element tile, so DMA, ring and bank
+// behaviour carry over -- and ONE MFMA per (16 x 16) fragment pair consumes it whole: 32 MFMAs of 2 x 16 x 16 x 128 flop per
+// wave and K-tile, each twice as long as a bf16 16x16x32 one, i.e. the same MFMA time per K-tile for twice the K depth.
+//
+// Operand fragment: lane (l15 = lane & 15, q = lane >> 4) holds row l15, K-elements [32 q, 32 q + 32) = two ds_read_b128.
+// To keep the bf16 kernel's conflict-free read pattern (16-byte chunk (4 j + q) ^ swz(row) for read j), the DMA puts global
+// chunk 2 q + j at that LDS position: a rotation of the 3-bit chunk index on the SOURCE address, full 128-byte lines still.
+//
+// K-tile schedule (4 steps of 8 MFMAs; A fragments in two sets of two, W fragments in ONE set of four that is reloaded
+// fragment by fragment behind its last use):
+//   S0  A1 <- m-frags 2,3     MFMA (n 0..3) x (m 0,1), n-major, waiting for W[n] one fragment at a time   + DMA of tile i+1
+//   S1  A0 <- m-frags 4,5     MFMA x (m 2,3)
+//   S2  A1 <- m-frags 6,7     MFMA x (m 4,5)
+//       wait: own DMA pieces + scale load of tile i+1 landed, own reads done; tile barrier
+//   S3  A0 <- tile i+1 m 0,1  MFMA x (m 6,7), n-major; W[n] <- tile i+1 right behind its two MFMAs  + DMA of tile i+2
+#include <cstring>
+#include <type_traits>
+
+#include "dk_kernels.h"
+
+#ifndef DK_F8_SAFE
+#define DK_F8_SAFE 0  // lab / debugging: every LDS wait is lgkmcnt(0)
+#endif
+
+#define T256 256
+#define BKB 128                      // bytes (= fp8 elements) of a row per K-tile
+#define HALF_BYTES (128 * BKB)       // 128 rows
+#define KT_BYTES (4 * HALF_BYTES)    // A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255
+#define LDS_BYTES (2 * KT_BYTES)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// position of block `bid` inside the XCD-contiguous order of `count` blocks (hardware places block b on XCD b & 7)
+__device__ __forceinline__ int f8_xcd_contiguous(int bid, int count) {
+  const int x = bid & 7;
+  int start = 0;
+  for (int y = 0; y < x; ++y) start += y < count ? (count - y + 7) >> 3 : 0;
+  return start + (bid >> 3);
+}
+
+__global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, GemmF8Params pb, int tiles_a, int tiles_b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const int tile = f8_xcd_contiguous(blockIdx.x, tiles_a + tiles_b);
+  const bool second = tile >= tiles_a;
+  const GemmF8Params& p = second ? pb : pa;
+  const int tl = second ? tile - tiles_a : tile;
+  const int nk = p.K / BKB;
+  const int nbm = (p.M + T256 - 1) / T256, nbn = p.N / T256;
+
+  // lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), read j = position (4 j + q) ^ swz(row)
+  unsigned offk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) offk[j] = (unsigned)(l15 * 128 + (((j * 4 + q) ^ (l15 >> 1)) << 4));
+  const unsigned sA = wm * HALF_BYTES;
+  const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
+
+  const int srow = lane >> 3;
+  const int GROUP = 4;
+  const int tpg = GROUP * nbn;
+  const int g = tl / tpg;
+  const int first_m = g * GROUP;
+  const int gsz = min(nbm - first_m, GROUP);
+  const int tm = first_m + (tl % tpg) % gsz;
+  const int tn = (tl % tpg) / gsz;
+  const int m0 = tm * T256, n0 = tn * T256;
+
+  // DMA sources.  LDS position t (after the row swizzle) of a row takes global chunk rot(t) = 2 (t & 3) + (t >> 2)
+  unsigned la[2][2], lw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane & 7) ^ swz(row), row = wave * 16 + j * 8 + srow
+    const int chunk = ((t & 3) << 1) | (t >> 2);
+    lw[j] = (unsigned)srow * (unsigned)p.ldw + chunk * 16;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int m = min(m0 + hh * 128 + wave * 16 + j * 8 + srow, p.M - 1);
+      const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
+      la[hh][j] = phys * (unsigned)p.lda + chunk * 16;
+    }
+  }
+  const char* gA = (const char*)p.A;
+  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw;
+  const size_t w128 = (size_t)128 * p.ldw, w8 = (size_t)8 * p.ldw;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
+  auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
+    const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
+    const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
+    if (op == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, (int)la[hh][j],
+                                               i * BKB, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, (int)lw[j],
+                                               (int)(hh * w128 + j * w8) + i * BKB, 0, 0);
+  };
+
+  // E8M0 scales of this wave's 128 A rows for one K-tile: 8 bytes per lane (byte mf = row mf * 16 + l15, block q), one
+  // coalesced 512-byte read per wave (layout: dk_mx_scale_index).  The wave's rows must be one aligned 128-row block of the
+  // physical buffer (checked by the launcher: segments and offsets are multiples of 128 rows).
+  const int mrow0 = m0 + wm * 128;
+  const unsigned a_blk = (unsigned)(((mrow0 / p.a_seg_len) * p.a_seg_stride + (mrow0 % p.a_seg_len) + p.a_row0) >> 7);
+  const unsigned char* sa_ptr = p.SA + ((size_t)a_blk * 64 + lane) * 8;
+  const size_t sa_step = (size_t)p.sa_nblk * 512;  // bytes between K-tiles
+  u32x2 sa_cur, sa_nxt;
+
+  f32x4 acc[4][8];  // [nf][mf]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#define F8_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+// the two m-fragments (MFA, MFA + 1) of a set: 4 reads
+#define F8_RDA(SET, BUFOFF, OFFA, OFFB)                 \
+  do {                                                  \
+    const unsigned a0_ = offk[0] + sA + (BUFOFF);       \
+    const unsigned a1_ = offk[1] + sA + (BUFOFF);       \
+    F8_RD(SET##lo[0], a0_, OFFA);                       \
+    F8_RD(SET##hi[0], a1_, OFFA);                       \
+    F8_RD(SET##lo[1], a0_, OFFB);                       \
+    F8_RD(SET##hi[1], a1_, OFFB);                       \
+  } while (0)
+#define F8_RDW(NF, BUFOFF, OFF)                         \
+  do {                                                  \
+    F8_RD(wlo[NF], offk[0] + sW + (BUFOFF), OFF);       \
+    F8_RD(whi[NF], offk[1] + sW + (BUFOFF), OFF);       \
+  } while (0)
+#if DK_F8_SAFE
+#define F8_CNT(N) "0"
+#else
+#define F8_CNT(N) #N
+#endif
+#define F8_WAIT2(N, A, B) asm volatile("s_waitcnt lgkmcnt(" F8_CNT(N) ")" : "+v"(A), "+v"(B))
+#define F8_WAIT4(N, A, B, C_, D_) asm volatile("s_waitcnt lgkmcnt(" F8_CNT(N) ")" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_))
+#define F8_WAIT6(N, A, B, C_, D_, E_, F_) \
+  asm volatile("s_waitcnt lgkmcnt(" F8_CNT(N) ")" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_), "+v"(E_), "+v"(F_))
+// the wait in front of the tile barrier: own fragment reads, own DMA pieces and the scale load of the next K-tile
+#define F8_TILE_WAIT(A, B, C_, D_, S_) \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_), "+v"(S_)::"memory")
+#define F8_FRAG(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
+// one MFMA: acc[NF][MF] += W[NF] . A(SET)[AI]; scale of the activation rows = byte (MF & 3) of sa_cur[MF >> 2]
+#define F8_MM(NF, SET, AI, MF)                                                                                              \
+  do {                                                                                                                      \
+    acc[NF][MF] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(F8_FRAG(wlo[NF], whi[NF]), F8_FRAG(SET##lo[AI], SET##hi[AI]), \
+                                                                   acc[NF][MF], 0, 0, 0, 0x7F7F7F7F, (MF) & 3, (int)sa_cur[(MF) >> 2]); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  } while (0)
+// DMA piece G of K-tile TILE in front of MFMA slot SLOT of a step, when this wave group's phase PH puts it there
+#define F8_PIECE(ON, TILE, G0, SLOT, PH)                                                    \
+  do {                                                                                      \
+    if ((ON) && (SLOT) >= (PH) && (((SLOT) - (PH)) & 1) == 0 && (((SLOT) - (PH)) >> 1) < 4) \
+      issue_piece((TILE), (G0) + (((SLOT) - (PH)) >> 1));                                   \
+  } while (0)
+// One K-tile.  ON1 / ON2 (compile-time): whether the DMA pieces (and scales) of K-tile i+1 (second half) / i+2 (first half)
+// are issued -- false only in the last two K-tiles, so that the steady-state loop carries no branches around them.
+#define F8_ITER(PH, ON1, ON2)                                                                                       \
+  {                                                                                                                 \
+    const unsigned bo = (i & 1) * KT_BYTES;                                                                         \
+    /* ---- S0: (n 0..3) x (m 0,1) ---- */                                                                         \
+    F8_WAIT6(6, a0lo[0], a0hi[0], a0lo[1], a0hi[1], wlo[0], whi[0]);                                                \
+    F8_RDA(a1, bo, 4096, 6144);                                                                                     \
+    if (ON1) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_nxt) : "v"(sa_ptr + (size_t)(i + 1) * sa_step) : "memory"); \
+    F8_PIECE(ON1, i + 1, 4, 0, PH); F8_MM(0, a0, 0, 0);                                                             \
+    F8_PIECE(ON1, i + 1, 4, 1, PH); F8_MM(0, a0, 1, 1);                                                             \
+    F8_WAIT2(8, wlo[1], whi[1]);                                                                                    \
+    F8_PIECE(ON1, i + 1, 4, 2, PH); F8_MM(1, a0, 0, 0);                                                             \
+    F8_PIECE(ON1, i + 1, 4, 3, PH); F8_MM(1, a0, 1, 1);                                                             \
+    F8_WAIT2(6, wlo[2], whi[2]);                                                                                    \
+    F8_PIECE(ON1, i + 1, 4, 4, PH); F8_MM(2, a0, 0, 0);                                                             \
+    F8_PIECE(ON1, i + 1, 4, 5, PH); F8_MM(2, a0, 1, 1);                                                             \
+    F8_WAIT2(4, wlo[3], whi[3]);                                                                                    \
+    F8_PIECE(ON1, i + 1, 4, 6, PH); F8_MM(3, a0, 0, 0);                                                             \
+    F8_PIECE(ON1, i + 1, 4, 7, PH); F8_MM(3, a0, 1, 1);                                                             \
+    /* ---- S1: x (m 2,3) ---- */                                                                                   \
+    F8_RDA(a0, bo, 8192, 10240);                                                                                    \
+    F8_WAIT4(4, a1lo[0], a1hi[0], a1lo[1], a1hi[1]);                                                                \
+    F8_MM(0, a1, 0, 2); F8_MM(0, a1, 1, 3); F8_MM(1, a1, 0, 2); F8_MM(1, a1, 1, 3);                                 \
+    F8_MM(2, a1, 0, 2); F8_MM(2, a1, 1, 3); F8_MM(3, a1, 0, 2); F8_MM(3, a1, 1, 3);                                 \
+    /* ---- S2: x (m 4,5) ---- */                                                                                   \
+    F8_RDA(a1, bo, 12288, 14336);                                                                                   \
+    F8_WAIT4(4, a0lo[0], a0hi[0], a0lo[1], a0hi[1]);                                                                \
+    F8_MM(0, a0, 0, 4); F8_MM(0, a0, 1, 5); F8_MM(1, a0, 0, 4); F8_MM(1, a0, 1, 5);                                 \
+    F8_MM(2, a0, 0, 4); F8_MM(2, a0, 1, 5); F8_MM(3, a0, 0, 4); F8_MM(3, a0, 1, 5);                                 \
+    F8_TILE_WAIT(a1lo[0], a1hi[0], a1lo[1], a1hi[1], sa_nxt);                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                   \
+    asm volatile("" ::: "memory");                                                                                  \
+    /* ---- S3: x (m 6,7); next tile's first A set and, fragment by fragment, its W set ---- */                     \
+    F8_RDA(a0, bo ^ KT_BYTES, 0, 2048);  /* unconditional: after the last tile these read stale ring data nobody uses */ \
+    F8_PIECE(ON2, i + 2, 0, 0, PH); F8_MM(0, a1, 0, 6);                                                             \
+    F8_PIECE(ON2, i + 2, 0, 1, PH); F8_MM(0, a1, 1, 7);                                                             \
+    F8_RDW(0, bo ^ KT_BYTES, 0);                                                                                    \
+    F8_PIECE(ON2, i + 2, 0, 2, PH); F8_MM(1, a1, 0, 6);                                                             \
+    F8_PIECE(ON2, i + 2, 0, 3, PH); F8_MM(1, a1, 1, 7);                                                             \
+    F8_RDW(1, bo ^ KT_BYTES, 2048);                                                                                 \
+    F8_PIECE(ON2, i + 2, 0, 4, PH); F8_MM(2, a1, 0, 6);                                                             \
+    F8_PIECE(ON2, i + 2, 0, 5, PH); F8_MM(2, a1, 1, 7);                                                             \
+    F8_RDW(2, bo ^ KT_BYTES, 4096);                                                                                 \
+    F8_PIECE(ON2, i + 2, 0, 6, PH); F8_MM(3, a1, 0, 6);                                                             \
+    F8_PIECE(ON2, i + 2, 0, 7, PH); F8_MM(3, a1, 1, 7);                                                             \
+    F8_RDW(3, bo ^ KT_BYTES, 6144);                                                                                 \
+    sa_cur = sa_nxt;                                                                                                \
+  }
+// everything in flight at a section boundary is waited for there (an inline-asm load must not be live across a
+// compiler-visible merge)
+#define F8_DRAIN()                                                                                                  \
+  do {                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0lo[0]), "+v"(a0hi[0]), "+v"(a0lo[1]), "+v"(a0hi[1]));              \
+    asm volatile("" : "+v"(wlo[0]), "+v"(whi[0]), "+v"(wlo[1]), "+v"(whi[1]));                                      \
+    asm volatile("" : "+v"(wlo[2]), "+v"(whi[2]), "+v"(wlo[3]), "+v"(whi[3]));                                      \
+  } while (0)
+#define F8_DRIVE(PH)                                     \
+  {                                                      \
+    int i = 0;                                           \
+    for (; i + 2 < nk; ++i) F8_ITER(PH, true, true)      \
+    F8_DRAIN();                                          \
+    if (i + 1 < nk) {                                    \
+      F8_ITER(PH, true, false)                           \
+      ++i;                                               \
+      F8_DRAIN();                                        \
+    }                                                    \
+    F8_ITER(PH, false, false)                            \
+    F8_DRAIN();                                          \
+  }
+
+  {
+    i32x4 wlo[4], whi[4], a0lo[2], a0hi[2], a1lo[2], a1hi[2];
+    // prologue: scales of K-tile 0, K-tile 0 completely, and the first half of K-tile 1 (the loop issues the rest in S0)
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_cur) : "v"(sa_ptr) : "memory");
+#pragma unroll
+    for (int gidx = 0; gidx < 8; ++gidx) issue_piece(0, gidx);
+    if (nk > 1) {
+#pragma unroll
+      for (int gidx = 0; gidx < 4; ++gidx) issue_piece(1, gidx);
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(sa_cur)::"memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa_cur)::"memory");
+    }
+    sa_nxt = sa_cur;  // (behind the wait: the copy must not read the register before the load has landed)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not be live across
+    //  a compiler-visible branch)
+    if (wm == 0) {
+      F8_RDA(a0, 0u, 0, 2048);
+      F8_RDW(0, 0u, 0); F8_RDW(1, 0u, 2048); F8_RDW(2, 0u, 4096); F8_RDW(3, 0u, 6144);
+      F8_DRIVE(0)
+    } else {
+      F8_RDA(a0, 0u, 0, 2048);
+      F8_RDW(0, 0u, 0); F8_RDW(1, 0u, 2048); F8_RDW(2, 0u, 4096); F8_RDW(3, 0u, 6144);
+      F8_DRIVE(1)
+    }
+  }
+#undef F8_RD
+#undef F8_RDA
+#undef F8_RDW
+#undef F8_WAIT2
+#undef F8_WAIT4
+#undef F8_WAIT6
+#undef F8_TILE_WAIT
+#undef F8_MM
+#undef F8_PIECE
+#undef F8_ITER
+#undef F8_DRAIN
+#undef F8_DRIVE
+
+  // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
+  // All waves passed the last loop barrier after their final ds_read of live data, so the ring is free.
+  const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
+  void* const Cb = out2 ? p.C2 : p.C;
+  const int ldcb = out2 ? p.ldc2 : p.ldc;
+  const int epi = out2 ? p.epi2 : p.epi;
+  const bool out_mx8 = out2 ? p.c2_mx8 != 0 : p.c_mx8 != 0;
+  const int ncol0 = out2 ? n0 - p.n_split : n0;
+  const bool has_res = epi == DK_EPI_GATE_RES || epi == DK_EPI_RES;
+  auto inside = [&](int len) { return m0 / len == (m0 + T256 - 1) / len; };
+  const bool fast = m0 + T256 <= p.M && inside(p.c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
+                    (epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
+  const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
+  const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128 : 0;
+  const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
+  const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
+  const int rrow = lane >> 2, rc2 = (lane & 3) * 2;
+
+  auto unpack8 = [](const uint4 v, float* f) {
+    unpack2bf(v.x, f[0], f[1]);
+    unpack2bf(v.y, f[2], f[3]);
+    unpack2bf(v.z, f[4], f[5]);
+    unpack2bf(v.w, f[6], f[7]);
+  };
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) {
+        const int row = mf * 16 + l15;
+        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
+      }
+    const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual, wscale)
+    const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ws8[8];
+    if (p.bias) unpack8(*(const uint4*)(p.bias + col), bias8);
+    {
+      const f32x4 w0 = *(const f32x4*)(p.wscale + col), w1 = *(const f32x4*)(p.wscale + col + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ws8[e] = w0[e], ws8[4 + e] = w1[e];
+    }
+    auto rows = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      if (FAST && epi == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
+      int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
+      if (!FAST) {
+        const int ms = mrow0 + rrow;
+        c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
+        if (has_res) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
+        if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
+      }
+#pragma unroll 4
+      for (int itr = 0; itr < 8; ++itr) {
+        const int row = itr * 16 + rrow;  // row inside the wave's 128-row block
+        size_t crow = physC0 + row, rrow_phys = physR0 + row;
+        bool valid = true;
+        if (!FAST) {
+          valid = mrow0 + row < p.M;
+          crow = (size_t)c_seg * p.c_seg_stride + c_rem;
+          rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
+          if (epi == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
+          for (c_rem += 16; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
+          if (has_res)
+            for (r_rem += 16; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
+          if (epi == DK_EPI_GATE_RES)
+            for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
+        }
+        const unsigned sw = (unsigned)((row >> 1) & 7);
+        const f32x4 a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
+        const f32x4 a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vv[e] = round_bf16(a0[e] * ws8[e] + bias8[e]);
+          vv[4 + e] = round_bf16(a1[e] * ws8[4 + e] + bias8[4 + e]);
+        }
+        if (epi == DK_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = gelu_erf_f(vv[e]);
+        } else if (epi == DK_EPI_BIAS_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
+        } else if (has_res) {
+          uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
+          float r8[8];
+          unpack8(rr, r8);
+          if (epi == DK_EPI_GATE_RES) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] = r8[e] + round_bf16(gate8[e] * vv[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] += r8[e];
+          }
+        }
+        if (out_mx8) {
+          // MX-fp8 output: the four lanes of a row hold one 32-column block; values are rounded to bf16 first (what the bf16
+          // path would have stored), then quantised -- 8 bytes per lane, one scale byte per block
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = round_bf16(vv[e]);
+          unsigned e8;
+          const uint2 q8 = dk_mx8_quantize8(vv, e8);
+          if (FAST || valid) {
+            *(uint2*)((unsigned char*)Cb + crow * (size_t)ldcb + ocol) = q8;
+            if ((lane & 3) == 0)
+              p.SC[dk_mx_scale_index((unsigned)crow + (unsigned)p.c_row0, (unsigned)(p.sc_kb0 + (ocol >> 5)), (unsigned)p.sc_nblk)] = (unsigned char)e8;
+          }
+        } else {
+          uint4 o4;
+          o4.x = pack2bf(vv[0], vv[1]);
+          o4.y = pack2bf(vv[2], vv[3]);
+          o4.z = pack2bf(vv[4], vv[5]);
+          o4.w = pack2bf(vv[6], vv[7]);
+          if (FAST || valid) *(uint4*)((bf16_t*)Cb + crow * (size_t)ldcb + ocol) = o4;
+        }
+      }
+    };
+    if (fast)
+      rows(std::true_type{});
+    else
+      rows(std::false_type{});
+  }
+}
+
+bool dk_gemm256f8_eligible(const GemmF8Params& p) {
+  if (p.M <= 0 || p.N % 256 != 0 || p.K % BKB != 0 || p.lda % 16 != 0 || p.ldw % 16 != 0 || p.lda < p.K || p.ldw < p.K) return false;
+  if (p.A == nullptr || p.W == nullptr || p.SA == nullptr || p.wscale == nullptr || p.C == nullptr) return false;
+  if (p.n_split % 256 != 0 || (p.n_split > 0 && (p.C2 == nullptr || p.n_split >= p.N))) return false;
+  if (p.a_seg_len <= 0 || p.c_seg_len <= 0) return false;
+  // scale reads: every wave's 128 rows are one aligned 128-row block of the A buffer
+  if (p.a_seg_len % 128 != 0 || p.a_seg_stride % 128 != 0 || p.a_row0 % 128 != 0 || p.sa_nblk <= 0) return false;
+  const bool res1 = p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES;
+  const bool res2 = p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES);
+  if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 8 != 0)) return false;
+  if ((p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES)) && (p.gate == nullptr || p.gate_seg_len <= 0)) return false;
+  // outputs: bf16 rows of 16-byte stores, or MX-fp8 rows of 8-byte stores with the scale side array
+  auto al = [](const void* q, int a) { return ((uintptr_t)q & (uintptr_t)(a - 1)) == 0; };
+  if (p.c_mx8 ? (p.ldc % 8 != 0 || !al(p.C, 8)) : (p.ldc % 8 != 0 || !al(p.C, 16))) return false;
+  if (p.n_split > 0 && (p.c2_mx8 ? (p.ldc2 % 8 != 0 || !al(p.C2, 8)) : (p.ldc2 % 8 != 0 || !al(p.C2, 16)))) return false;
+  if ((p.c_mx8 || (p.n_split > 0 && p.c2_mx8)) && (p.SC == nullptr || p.sc_nblk <= 0)) return false;
+  if (!al(p.res, 16) || !al(p.bias, 16) || !al(p.gate, 16) || !al(p.wscale, 16) || (p.gate != nullptr && p.gate_stride % 8 != 0)) return false;
+  // 32-bit byte offsets on the DMA side
+  const size_t a_rows = (size_t)((p.M - 1) / p.a_seg_len) * p.a_seg_stride + (size_t)((p.M - 1) % p.a_seg_len) + 1;
+  return a_rows * (size_t)p.lda < (1ull << 32) && (size_t)p.ldw * 8 < (1ull << 31);
+}
+
+// tile-parallel launch of `p` and, optionally, a second problem `p2` with the same N, K and epilogues
+int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream_t stream) {
+  DK_REQUIRE(dk_gemm256f8_eligible(p), "gemm256f8: shape / strides / scale layout not eligible");
+  if (p2) {
+    DK_REQUIRE(dk_gemm256f8_eligible(*p2), "gemm256f8: second problem not eligible");
+    DK_REQUIRE(p2->N == p.N && p2->K == p.K && p2->epi == p.epi && p2->n_split == p.n_split && p2->c_mx8 == p.c_mx8 &&
+                   (p.n_split == 0 || (p2->epi2 == p.epi2 && p2->c2_mx8 == p.c2_mx8)),
+               "grouped fp8 GEMM: N, K, epilogue must match");
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256f8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
+  const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;
+  double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
+  dk_prof_begin(3, work, stream);
+  hipLaunchKernelGGL(dk_gemm256f8_kernel, dim3(tiles_a + tiles_b), dim3(512), LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b);
+  dk_prof_end(stream);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

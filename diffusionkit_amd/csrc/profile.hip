@@ -10,14 +10,16 @@ std::vector<Rec> g_pool;
 size_t g_used = 0;
 bool g_on = false;
 bool g_open = false;
-const size_t kPool = 16384;
+size_t g_dropped = 0;  // launches that found no event pair (creation failed or the hard cap below): dk_profile_read fails then
+const size_t kPool = size_t(1) << 22;  // grows on demand (a 20-image FLUX replay records ~18 000 launches); the cap only bounds a runaway
 }  // namespace
 
 void dk_prof_begin(int cls, double work, hipStream_t st) {
-  if (!g_on || g_used >= kPool) return;
+  if (!g_on) return;
+  if (g_used >= kPool) { ++g_dropped; return; }
   if (g_pool.size() <= g_used) {
     Rec r;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { ++g_dropped; return; }
     g_pool.push_back(r);
   }
   g_pool[g_used].cls = cls;
@@ -36,10 +38,12 @@ extern "C" int dk_profile_enable(int32_t on) {
   g_on = on != 0;
   g_used = 0;
   g_open = false;
+  g_dropped = 0;
   return 0;
 }
 extern "C" int dk_profile_read(int32_t cls, double* total_ms, double* total_work, int64_t* launches) {
   DK_REQUIRE(total_ms && total_work && launches, "null argument");
+  DK_REQUIRE(g_dropped == 0, "profile: launches were not recorded (event pool exhausted); the totals would under-report");
   double ms = 0.0, work = 0.0;
   int64_t n = 0;
   for (size_t i = 0; i < g_used; ++i) {

@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 from .weights import blob_pack, blob_unpack
 
-_CHUNK_ELEMS = 1 << 31  # 4 GiB of bf16 per broadcast call
+_CHUNK_ELEMS = 1 << 32  # bytes per broadcast call (4 GiB)
 
 
 def init_distributed(backend: Optional[str] = None) -> tuple:
@@ -46,9 +46,9 @@ def shard_seeds(seeds: Sequence[int], rank: int, world: int) -> List[int]:
 
 def broadcast_weights(packed: Optional[Dict[str, torch.Tensor]], device, src: int = 0,
                       chunk_elems: int = _CHUNK_ELEMS) -> Dict[str, torch.Tensor]:
-    """Root packs its engine tensors into one bf16 blob; every rank receives blob + index and
-    rebuilds zero-copy views.  One collective per ``chunk_elems`` elements (4 GiB by default: the FLUX blob of
-    11.9 G elements goes out in 6 calls)."""
+    """Root packs its engine tensors into one byte blob; every rank receives blob + index and
+    rebuilds zero-copy views.  One collective per ``chunk_elems`` bytes (4 GiB by default: the bf16 FLUX blob of
+    23.8 GB goes out in 6 calls)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         assert packed is not None
         return packed
@@ -61,21 +61,36 @@ def broadcast_weights(packed: Optional[Dict[str, torch.Tensor]], device, src: in
     dist.broadcast_object_list(meta, src=src)
     index, numel = meta
     if rank != src:
-        blob = torch.empty(numel, dtype=torch.bfloat16, device=device)
+        blob = torch.empty(numel, dtype=torch.uint8, device=device)
     for off in range(0, numel, chunk_elems):
         dist.broadcast(blob[off:off + chunk_elems], src=src)
     return blob_unpack(blob, index)
 
 
 def gather_images(u8: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
-    """Gather each rank's [n_img, H, W, 3] uint8 images on ``dst`` (None elsewhere)."""
+    """Gather each rank's [n_img, H, W, 3] uint8 images on ``dst`` (None elsewhere).  ``shard_seeds`` hands ranks unequal
+    image counts whenever the number of seeds is not a multiple of the world size (a rank may hold none), and a collective
+    needs equal shapes: the per-rank counts are exchanged first, every rank pads its block to the largest count, and the
+    padding is cut off on ``dst``."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [u8]
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    count = torch.tensor([u8.shape[0]], dtype=torch.int64, device=u8.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n_max == 0:
+        return [u8[:0] for _ in range(world)] if rank == dst else None
+    block = u8
+    if u8.shape[0] < n_max:
+        block = torch.zeros(n_max, *u8.shape[1:], dtype=u8.dtype, device=u8.device)
+        block[:u8.shape[0]] = u8
+    block = block.contiguous()
     if dist.get_backend() == "nccl":
-        out = [torch.empty_like(u8) for _ in range(world)]
-        dist.all_gather(out, u8)  # RCCL has no gather-to-one primitive cheaper than this at 3 MiB/image
-        return out if dist.get_rank() == dst else None
-    out = [torch.empty_like(u8) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(u8, out, dst=dst)
-    return out
+        out = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(out, block)  # RCCL has no gather-to-one primitive cheaper than this at 3 MiB/image
+        return [o[:c] for o, c in zip(out, counts)] if rank == dst else None
+    out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+    dist.gather(block, out, dst=dst)
+    return [o[:c] for o, c in zip(out, counts)] if rank == dst else None

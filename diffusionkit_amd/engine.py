@@ -60,13 +60,19 @@ class MMDiTEngine:
         c.frequency_embed_dim, c.max_period = config.frequency_embed_dim, config.max_period
         c.embed_dtype = _EMBED_DTYPE[config.dtype]
         c.layer_norm_eps = config.layer_norm_eps
+        c.guidance_embed = int(config.guidance_embed)
+        if config.weight_dtype not in ("bfloat16", "fp8_e4m3"):
+            raise _lib.DkHipError(f"unknown weight_dtype {config.weight_dtype!r} (bfloat16 | fp8_e4m3)")
+        c.fp8_linears = int(config.weight_dtype == "fp8_e4m3")
         h = C.c_void_p()
         _lib.check(self.lib.dk_mmdit_create(C.byref(c), C.byref(h)), "dk_mmdit_create")
         self._h = h
         self.weights = packed_weights  # keep the device tensors alive
         for name, t in packed_weights.items():
-            _require_cuda(t, name, torch.bfloat16)
+            want = torch.uint8 if name.endswith(".weight_fp8") else torch.float32 if name.endswith(".wscale") else torch.bfloat16
+            _require_cuda(t, name, want)
             _lib.check(self.lib.dk_mmdit_bind(self._h, name.encode(), t.data_ptr()), f"bind {name}")
+        self.guidance = 3.5  # FLUX.1-dev's default distilled-guidance strength; only read when config.guidance_embed
         self._shape = None
         self._ws = None
         self._n_cached = 0
@@ -81,10 +87,13 @@ class MMDiTEngine:
         binds bare pointers, so the layout the packer produced is checked here, where the shapes are still known."""
         h, r = self.config.hidden_size, self.config.mlp_ratio
         for name, t in self.weights.items():
-            k = r * h if name.endswith(".mlp.fc2.weight") else (1 + r) * h if name.endswith(".linear2.weight") else 0
-            if k and t.shape[1] != self.lib.dk_weight_pitch(k):
+            fp8 = name.endswith(".weight_fp8")
+            base = name[:-len(".weight_fp8" if fp8 else ".weight")] if (fp8 or name.endswith(".weight")) else ""
+            k = r * h if base.endswith(".mlp.fc2") else (1 + r) * h if base.endswith(".linear2") else 0
+            pitch = (self.lib.dk_weight_pitch_fp8 if fp8 else self.lib.dk_weight_pitch)(k) if k else 0
+            if k and t.shape[1] != pitch:
                 raise _lib.DkHipError(f"{name}: {t.shape[1]} elements per row, the engine expects dk_weight_pitch({k}) = "
-                                      f"{self.lib.dk_weight_pitch(k)} (was the weight packed under a different pitch_min_k?)")
+                                      f"{pitch} (was the weight packed under a different pitch_min_k?)")
 
     # -- shape / workspace ---------------------------------------------------------------
     def prepare(self, batch: int, latent_size: Sequence[int], text_len: int, n_timesteps: int) -> None:
@@ -128,6 +137,8 @@ class MMDiTEngine:
         if pooled.shape != (self._shape[0], self.config.pooled_text_embed_dim):
             raise _lib.DkHipError(f"pooled_text_embeddings shape {tuple(pooled.shape)} != (batch, pooled_dim)")
         ts = [float(t) for t in timesteps]
+        if self.config.guidance_embed:
+            _lib.check(self.lib.dk_mmdit_set_guidance(self._h, float(self.guidance)), "dk_mmdit_set_guidance")
         arr = (C.c_float * len(ts))(*ts)
         _lib.check(self.lib.dk_mmdit_cache_modulation_params(self._h, pooled.data_ptr(), arr, len(ts), _stream()),
                    "dk_mmdit_cache_modulation_params")

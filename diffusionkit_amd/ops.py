@@ -190,3 +190,66 @@ def transpose(x: Tensor) -> Tensor:
     y = torch.empty(x.shape[1], x.shape[0], dtype=BF, device=x.device)
     _lib.check(lib.dk_transpose_bf16(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()), "dk_transpose_bf16")
     return y
+
+
+# ---- fp8 path (include/dk_hip.h: dk_gemm_fp8 / dk_quantize_mx8 / dk_ln_modulate_mx8) ----------------------------------
+def mx_scale_bytes(rows: int, k: int) -> int:
+    return int(_lib.load().dk_mx_scale_bytes(rows, k))
+
+
+def quantize_mx8(x: Tensor, out: Optional[Tensor] = None, scales: Optional[Tensor] = None, out_row0: int = 0, out_col0: int = 0):
+    """bf16 [M, h] -> MX-fp8: (e4m3 bytes uint8 [rows, ldo], scale side array uint8).  Fresh buffers hold exactly the M rows."""
+    _require_cuda(x, "x", BF)
+    M, h = x.shape
+    if out is None:
+        out = torch.zeros(M, h, dtype=torch.uint8, device=x.device)
+    if scales is None:
+        scales = torch.zeros(mx_scale_bytes(out.shape[0], out.shape[1]), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().dk_quantize_mx8(x.data_ptr(), x.stride(0), M, h, out.data_ptr(), out.stride(0), scales.data_ptr(),
+                                           out.shape[0], out_row0, out_col0, _stream()), "dk_quantize_mx8")
+    return out, scales
+
+
+def ln_modulate_mx8(x: Tensor, shift: Tensor, scale: Tensor, mod_seg_len: int = 0, eps: float = 1e-6):
+    """dk_ln_modulate_bf16 with an MX-fp8 output row: (e4m3 bytes [M, h], scale side array)."""
+    for n, t in (("x", x), ("shift", shift), ("scale", scale)):
+        _require_cuda(t, n, BF)
+    M, h = x.shape
+    out = torch.zeros(M, h, dtype=torch.uint8, device=x.device)
+    scales = torch.zeros(mx_scale_bytes(M, h), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().dk_ln_modulate_mx8(x.data_ptr(), x.stride(0), M, h, shift.data_ptr(), scale.data_ptr(), shift.stride(0),
+                                              mod_seg_len, eps, out.data_ptr(), h, scales.data_ptr(), M, 0, _stream()), "dk_ln_modulate_mx8")
+    return out, scales
+
+
+def gemm_fp8(a8: Tensor, a_scales: Tensor, w8: Tensor, w_scale: Tensor, bias: Optional[Tensor] = None, epilogue: int = DK_EPI_BIAS,
+             gate: Optional[Tensor] = None, res: Optional[Tensor] = None, gate_seg_len: int = 0, M: Optional[int] = None,
+             k: Optional[int] = None, out_mx8: bool = False):
+    """dk_gemm_fp8 over the first M rows / k columns of an MX-fp8 activation buffer a8 [rows, lda] and an e4m3 weight w8 [N, ldw].
+    Returns bf16 [M, N], or with ``out_mx8`` (e4m3 bytes [M, N], scale side array)."""
+    lib = _lib.load()
+    for n, t, dt in (("a8", a8, torch.uint8), ("a_scales", a_scales, torch.uint8), ("w8", w8, torch.uint8), ("w_scale", w_scale, torch.float32)):
+        _require_cuda(t, n, dt)
+    M = a8.shape[0] if M is None else M
+    K = a8.shape[1] if k is None else k
+    N = w8.shape[0]
+    d = _lib.dk_gemm_fp8_desc()
+    d.A, d.A_scales, d.W, d.w_scale = a8.data_ptr(), a_scales.data_ptr(), w8.data_ptr(), w_scale.data_ptr()
+    d.bias, d.gate, d.res = _ptr(bias), _ptr(gate), _ptr(res)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldw = a8.stride(0), w8.stride(0)
+    d.a_row0, d.a_rows = 0, a8.shape[0]
+    d.ldr = res.stride(0) if res is not None else 0
+    d.gate_seg_len = gate_seg_len
+    d.gate_stride = gate.stride(0) if gate is not None else 0
+    d.epilogue = epilogue
+    if out_mx8:
+        out = torch.zeros(M, N, dtype=torch.uint8, device=a8.device)
+        sc = torch.zeros(mx_scale_bytes(M, N), dtype=torch.uint8, device=a8.device)
+        d.C, d.ldc, d.c_mx8, d.C_scales, d.c_rows, d.c_row0, d.c_col0 = out.data_ptr(), N, 1, sc.data_ptr(), M, 0, 0
+        _lib.check(lib.dk_gemm_fp8(C.byref(d), _stream()), "dk_gemm_fp8")
+        return out, sc
+    out = torch.empty(M, N, dtype=BF, device=a8.device)
+    d.C, d.ldc = out.data_ptr(), N
+    _lib.check(lib.dk_gemm_fp8(C.byref(d), _stream()), "dk_gemm_fp8")
+    return out

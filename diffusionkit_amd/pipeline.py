@@ -104,6 +104,10 @@ class DiffusionPipeline:
         self.float16_dtype = torch.bfloat16
         self.dtype = torch.bfloat16
         self.activation_dtype = torch.bfloat16
+        # The model timesteps are host floats rounded to the REFERENCE pipeline's 16-bit dtype (quirk Q1): mx.float16 for
+        # DiffusionPipeline (mlx/__init__.py:76-79,683,770), mx.bfloat16 for FluxPipeline (:610-613) -- 857.69 -> 857.5 in
+        # fp16, 856 in bf16; the adaLN table is computed on these values.
+        self.timestep_dtype = torch.bfloat16 if self._IS_FLUX else torch.float16
         self.use_t5 = use_t5
         self.mmdit_ckpt = MMDIT_CKPT[model_version]  # KeyError on unknown versions, as the reference
         self.low_memory_mode = low_memory_mode
@@ -477,6 +481,32 @@ def to_d(x, sigma, denoised):
     return (x - denoised) / sigma
 
 
+def _tile_conditioning(conditioning: Tensor, pooled: Tensor, n_img: int, cfg_on: bool, is_flux: bool):
+    """Conditioning rows -> the engine's batch layout for ``n_img`` images denoised in one step loop (a seed list):
+    CFG on: [prompt x n_img, negative x n_img] (the layout dk_euler_cfg_step pairs up); CFG off: one prompt row per image.
+    Accepted inputs: the reference's rows ([prompt, negative] from encode_text for SD3, mlx/__init__.py:197-251; one row for
+    FLUX, :642-671), tiled here per image, or rows the caller already laid out per image (n_img, or 2 * n_img with CFG).
+    SD3 with CFG off keeps the prompt row (the reference cannot run that case)."""
+    n = conditioning.shape[0]
+    if pooled.shape[0] != n:
+        raise ValueError(f"conditioning has {n} rows, pooled conditioning {pooled.shape[0]}")
+
+    def rep(t, rows):
+        return torch.cat([t[r:r + 1].expand(n_img, *t.shape[1:]) for r in rows], 0)
+
+    if cfg_on:
+        if n == 2 * n_img and (n_img > 1 or n == 2):
+            return conditioning, pooled  # [prompt, negative] for one image, or laid out per image by the caller
+        if n == 2:
+            return rep(conditioning, (0, 1)), rep(pooled, (0, 1))
+        return conditioning, pooled  # mismatch: reported by the caller
+    if n == 2 and not is_flux:  # encode_text's [prompt, negative]: the negative row is unused without guidance
+        return rep(conditioning, (0,)), rep(pooled, (0,))
+    if n == 1 and n_img > 1:
+        return rep(conditioning, (0,)), rep(pooled, (0,))
+    return conditioning, pooled
+
+
 def sample_euler(model: CFGDenoiser, x: Tensor, sigmas, extra_args=None):
     """mlx/__init__.py:761-788.  x: fp32 [n_img,h,w,16] on the GPU (updated copy is returned);
     sigmas: host float32 array.  One device synchronisation per step (the reference's
@@ -493,16 +523,14 @@ def sample_euler(model: CFGDenoiser, x: Tensor, sigmas, extra_args=None):
         conditioning = conditioning.squeeze(2)
     n_img = x.shape[0]
     rows = n_img * (2 if cfg_on else 1)
-    if not cfg_on and conditioning.shape[0] != rows:
-        # SD3 with CFG off: the reference cannot run this; use the prompt row(s).
-        conditioning, pooled = conditioning[:rows], pooled[:rows]
+    conditioning, pooled = _tile_conditioning(conditioning, pooled, n_img, cfg_on, pipe._IS_FLUX)
     if conditioning.shape[0] != rows or pooled.shape[0] != rows:
         raise ValueError(f"conditioning batch {conditioning.shape[0]} does not match latent batch {rows}")
     conditioning = conditioning.to(pipe.device, torch.bfloat16).contiguous()
     pooled = pooled.to(pipe.device, torch.bfloat16).contiguous()
 
-    # model timesteps are sigma*1000 rounded to the activation dtype (quirk Q1)
-    timesteps = _round_to_dtype(pipe.sampler.timestep(sigmas), pipe.activation_dtype)
+    # model timesteps are sigma*1000 rounded to the reference pipeline's activation dtype (quirk Q1): fp16 for SD3, bf16 for FLUX
+    timesteps = _round_to_dtype(pipe.sampler.timestep(sigmas), pipe.timestep_dtype)
     mm.prepare(rows, x.shape[1:3], conditioning.shape[1], len(timesteps))
     model.cache_modulation_params(pooled, timesteps)
     mm.cache_context(conditioning)  # context_embedder is step-invariant (the reference recomputes it in every call, mmdit.py:195)

@@ -81,6 +81,9 @@ def synth_mmdit_weights(cfg: MMDiTConfig, seed: int = 1234, device="cpu", dtype=
         I.linear(f"{emb}.mlp.layers.0", h, d_in)
         I.linear(f"{emb}.mlp.layers.2", h, h)
     I.linear("context_embedder", h, cfg.token_level_text_embed_dim)
+    if cfg.guidance_embed:  # MLPEmbedder(in_dim=frequency_embed_dim, hidden_dim=hidden_size), mmdit.py:31-36,945-955
+        I.linear("guidance_in.mlp.layers.0", h, cfg.frequency_embed_dim)
+        I.linear("guidance_in.mlp.layers.2", h, h)
 
     def block(prefix, n_mod, skip_post=False, parallel=False):
         I.linear(prefix + ".attn.q_proj", h, h)
@@ -207,19 +210,59 @@ def adaln_order(cfg: MMDiTConfig):
     return names
 
 
+E4M3_MAX = 448.0
+
+
+def quantize_weight_e4m3(w: Tensor):
+    """[N, K] weight -> (e4m3 bytes as uint8 [N, K], fp32 scale [N]): one scale per output channel, scale = row amax / 448
+    (an all-zero row gets scale 1), elements = round-to-nearest-even(w / scale) in OCP e4m3.  The arithmetic runs in fp32 on
+    whatever device ``w`` lives on; ``dequantize_weight_e4m3`` gives back the values the fp8 GEMM multiplies with."""
+    wf = w.to(torch.float32)
+    amax = wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / E4M3_MAX, torch.ones_like(amax))
+    q = (wf / scale[:, None]).clamp_(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def dequantize_weight_e4m3(q: Tensor, scale: Tensor, k: int = None) -> Tensor:
+    """fp32 values of a quantised weight (pad columns of a pitched matrix cut off with ``k``)."""
+    w = q.view(torch.float8_e4m3fn).to(torch.float32) * scale.to(torch.float32)[:, None]
+    return w if k is None else w[:, :k]
+
+
+BLOCK_LINEARS = (".attn.qkv", ".attn.o_proj", ".mlp.fc1", ".mlp.fc2", ".linear1", ".linear2")  # what weight_dtype = "fp8_e4m3" quantises
+
+
 def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = False) -> Dict[str, Tensor]:
     """Reference-named weights -> engine tensors (bf16, contiguous, on ``device``).
-    ``consume=True`` pops source tensors as they are packed (halves peak memory at full size)."""
+    ``consume=True`` pops source tensors as they are packed (halves peak memory at full size).
+    With ``cfg.weight_dtype == "fp8_e4m3"`` the Linear matrices of the transformer blocks leave as
+    "<name>.weight_fp8" (uint8 e4m3, rows at dk_weight_pitch_fp8) + "<name>.wscale" (fp32) instead of "<name>.weight"."""
     dev = torch.device(device)
     bf = torch.bfloat16
+    fp8 = cfg.weight_dtype == "fp8_e4m3"
     out: Dict[str, Tensor] = {}
     get = (lambda k: w.pop(k)) if consume else (lambda k: w[k])
 
     def put(name, t):
+        if fp8 and name.endswith(".weight") and name[:-len(".weight")].endswith(BLOCK_LINEARS):
+            base = name[:-len(".weight")]
+            q, scale = quantize_weight_e4m3(t.to(device=dev, dtype=bf))  # the bf16 weight is what gets quantised
+            k = q.shape[1]
+            pitch = int(_lib.load().dk_weight_pitch_fp8(k))
+            if pitch != k:
+                padded = torch.zeros(q.shape[0], pitch, dtype=torch.uint8, device=dev)
+                padded[:, :k] = q
+                q = padded
+            out[base + ".weight_fp8"] = q.contiguous()
+            out[base + ".wscale"] = scale.contiguous()
+            return
         out[name] = t.to(device=dev, dtype=bf).contiguous()
 
     def put_pitched(name, t):
         """Long-reduction weights ([h, 4h] fc2, [h, 5h] linear2): rows at the engine's pitch (dk_weight_pitch, include/dk_hip.h)."""
+        if fp8:
+            return put(name, t)  # the fp8 branch of put() applies dk_weight_pitch_fp8
         k = t.shape[1]
         pitch = int(_lib.load().dk_weight_pitch(k))
         if pitch != k:
@@ -240,6 +283,10 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
               "t_embedder.mlp.layers.2.weight", "t_embedder.mlp.layers.2.bias",
               "final_layer.linear.weight", "final_layer.linear.bias"):
         put(k, get(k))
+    if cfg.guidance_embed:
+        for k in ("guidance_in.mlp.layers.0.weight", "guidance_in.mlp.layers.0.bias", "guidance_in.mlp.layers.2.weight",
+                  "guidance_in.mlp.layers.2.bias"):
+            put(k, get(k))
 
     put("adaLN.weight", torch.cat([get(n + ".adaLN_modulation.layers.1.weight").to(dev) for n in adaln_order(cfg)], dim=0))
     put("adaLN.bias", torch.cat([get(n + ".adaLN_modulation.layers.1.bias").to(dev) for n in adaln_order(cfg)], dim=0))
@@ -300,19 +347,20 @@ def pack_vae(cfg, w: Dict[str, Tensor], device) -> Dict[str, Tensor]:
 
 
 def blob_pack(tensors: Dict[str, Tensor]):
-    """Flatten a tensor dict into one contiguous bf16 blob + index (for a single RCCL broadcast)."""
+    """Flatten a tensor dict into one contiguous byte blob + index (for a single RCCL broadcast).  Tensors keep their dtype
+    (bf16 weights, uint8 e4m3 weights, fp32 scales): the blob is raw bytes, every tensor 256-byte aligned."""
     index, off = [], 0
     for k in sorted(tensors):
         t = tensors[k]
-        n = t.numel()
-        index.append((k, tuple(t.shape), off, n))
-        off += (n + 127) // 128 * 128  # keep every tensor 256-byte aligned
+        n = t.numel() * t.element_size()
+        index.append((k, tuple(t.shape), str(t.dtype).replace("torch.", ""), off, n))
+        off += (n + 255) // 256 * 256
     dev = next(iter(tensors.values())).device
-    blob = torch.zeros(off, dtype=torch.bfloat16, device=dev)
-    for k, shape, o, n in index:
-        blob[o:o + n] = tensors[k].reshape(-1)
+    blob = torch.zeros(off, dtype=torch.uint8, device=dev)
+    for k, shape, dt, o, n in index:
+        blob[o:o + n] = tensors[k].contiguous().reshape(-1).view(torch.uint8)
     return blob, index
 
 
 def blob_unpack(blob: Tensor, index) -> Dict[str, Tensor]:
-    return {k: blob[o:o + n].view(*shape) for k, shape, o, n in index}
+    return {k: blob[o:o + n].view(getattr(torch, dt)).view(*shape) for k, shape, dt, o, n in index}

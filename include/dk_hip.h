@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 1
+#define DK_ABI_VERSION 2
 
 int dk_abi_version(void);
 const char* dk_last_error(void);
@@ -123,6 +123,46 @@ int dk_text_elementwise(const void* a, const void* b, void* y, float* r, int64_t
 int dk_t5_bias_bf16(const void* emb, const int32_t* rel_bucket, int32_t H, int32_t S, int32_t ld, void* out,
                     void* stream);
 
+/* ---- fp8 path (BASELINE.json configs[3]: fp8 weights, CDNA4 block-scaled fp8 MFMA) -----------------------------------
+ * Weights: OCP e4m3 [N, K] + one f32 scale per output channel.  Activations: MX-fp8 = e4m3 [rows, K] + one E8M0 scale byte
+ * per row and 32 consecutive columns, the scale bytes in a side array of dk_mx_scale_bytes(rows, K) bytes whose layout is
+ * private to the library (written by dk_quantize_mx8 / dk_ln_modulate_mx8 / an MX-fp8 GEMM output, read by dk_gemm_fp8;
+ * tests/_fp8.py restates it).  Strides of fp8 buffers are in bytes.  No reference counterpart: the reference quantises
+ * weights to 4 bits with MLX (model_io.py:728-734) and keeps fp16 / bf16 activations. */
+typedef struct dk_gemm_fp8_desc {
+  const void* A;        /* e4m3 [rows, K], row stride lda; logical row m -> (m / a_seg_len) * a_seg_stride + m % a_seg_len */
+  const void* A_scales; /* scale side array of the BUFFER A points into                                                  */
+  const void* W;        /* e4m3 [N, K], row stride ldw                                                                   */
+  const float* w_scale; /* [N]                                                                                           */
+  void* C;              /* bf16 [., ldc], or with c_mx8: e4m3 [., ldc] + scales into C_scales                            */
+  const void* bias;     /* bf16 [N] or NULL                                                                              */
+  const void* gate;     /* as dk_gemm_desc                                                                               */
+  const void* res;
+  int32_t M, N, K;      /* N % 256 == 0, K % 128 == 0                                                                    */
+  int32_t lda, ldw, ldc, ldr;
+  int32_t a_seg_len, a_seg_stride; /* multiples of 128 rows                                                              */
+  int32_t a_row0;       /* physical row of its buffer that A points at (multiple of 128)                                 */
+  int32_t a_rows;       /* rows of the buffer A points into (sizes its scale array)                                      */
+  int32_t c_seg_len, c_seg_stride;
+  int32_t r_seg_len, r_seg_stride;
+  int32_t gate_seg_len, gate_stride;
+  int32_t epilogue;     /* DK_EPI_*                                                                                      */
+  int32_t c_mx8;        /* 1: MX-fp8 output (M % 256 == 0)                                                               */
+  void* C_scales;
+  int32_t c_rows, c_row0, c_col0; /* rows of the output buffer, physical row / column (multiple of 32) that C points at  */
+} dk_gemm_fp8_desc;
+int dk_gemm_fp8(const dk_gemm_fp8_desc* d, void* stream);
+size_t dk_mx_scale_bytes(int64_t rows, int32_t k);
+/* bf16 [M, h] (row stride ldx) -> MX-fp8 rows out_row0 .. of a [out_rows, ldo] e4m3 buffer at column out_col0 (multiple of 32) */
+int dk_quantize_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, void* out, int32_t ldo, void* out_scales,
+                    int64_t out_rows, int32_t out_row0, int32_t out_col0, void* stream);
+/* dk_ln_modulate_bf16 whose output row leaves as MX-fp8 (same arithmetic, same bf16 rounding, then quantised) */
+int dk_ln_modulate_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, const void* shift, const void* scale,
+                       int32_t mod_stride, int32_t mod_seg_len, float eps, void* out, int32_t ldo, void* out_scales,
+                       int64_t out_rows, int32_t out_row0, void* stream);
+/* row pitch in bytes of an fp8 matrix with k columns that is read with a long reduction (k + 128 from 8192 on, see dk_weight_pitch) */
+int32_t dk_weight_pitch_fp8(int32_t k);
+
 /* affine_transform + LayerNorm, mmdit.py:958-972, 838-849.
  * out[m,:] = LN(x[m,:]) * (1 + scale[b,:]) + shift[b,:], b = m / mod_seg_len. */
 int dk_ln_modulate_bf16(const void* x, int32_t ldx, void* out, int32_t ldo, int32_t M, int32_t h,
@@ -183,6 +223,16 @@ typedef struct dk_mmdit_config {
   int32_t pooled_text_embed_dim, token_level_text_embed_dim, frequency_embed_dim, max_period;
   int32_t embed_dtype; /* dtype the timestep embedding is evaluated in: 0 bf16, 1 fp16, 2 fp32 */
   float layer_norm_eps;
+  /* 1: the FLUX.1-dev guidance embedding (MLPEmbedder "guidance_in", mmdit.py:31-36,945-955, config.py:97-111) is added to
+   * the modulation vector; needs the guidance_in.mlp.layers.{0,2}.{weight,bias} tensors and dk_mmdit_set_guidance.
+   * 0 (the reference's behaviour: model_io.py:109 runs FLUX.1-dev on the schnell preset, quirk Q7): absent. */
+  int32_t guidance_embed;
+  /* 1: the Linear layers of the transformer blocks (q/k/v, o_proj, fc1, fc2, linear1, linear2) run on the fp8 MFMA with
+   * e4m3 weights ("<name>.weight_fp8" uint8 [N, dk_weight_pitch_fp8(K)] + "<name>.wscale" f32 [N] instead of
+   * "<name>.weight") and MX-fp8 activations quantised on the fly (BASELINE.json configs[3]; the reference's counterpart is
+   * its 4-bit nn.QuantizedLinear checkpoints, model_io.py:728-734,772-775).  Needs head_dim 128 and text / image token
+   * counts that are multiples of 128.  0: bf16 weights. */
+  int32_t fp8_linears;
 } dk_mmdit_config;
 
 typedef struct dk_mmdit dk_mmdit;
@@ -211,6 +261,11 @@ int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, int32_t laten
  * the activation dtype by the caller, quirk Q1). */
 int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled, const float* timesteps_host,
                                      int32_t n, void* stream);
+/* Guidance strength fed to the guidance embedding (configs with guidance_embed = 1; FLUX.1-dev's distilled guidance, 3.5 by
+ * default): the next dk_mmdit_cache_modulation_params adds guidance_in(timestep_embedding(1000 * guidance)) to every
+ * modulation vector -- the published FLUX.1-dev conditioning, which the reference's module tree declares (mmdit.py:31-36)
+ * but whose call site (:219-220) it never reaches (quirk Q7). */
+int dk_mmdit_set_guidance(dk_mmdit* m, float guidance);
 
 /* Step-invariant hoist of `self.context_embedder(token_level_text_embeddings)` (mmdit.py:195, recomputed by the reference
  * in every MMDiT.__call__): embeds `text` (bf16 [batch, S_t, text_dim]) once into the engine's workspace; later
@@ -263,7 +318,7 @@ int dk_latent_sample_f32(const void* moments_bf16, int32_t ldm, const float* noi
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference times phases with time.time(),
- * mlx/__init__.py:315-530).  When enabled, every GEMM (class 0), conv (1) and attention (2) launch
+ * mlx/__init__.py:315-530).  When enabled, every bf16 GEMM (class 0), conv (1), attention (2) and fp8 GEMM (3) launch
  * is bracketed by HIP events on its launch stream; dk_profile_read sums elapsed time, algorithmic
  * FLOPs and launch count of one class since the last dk_profile_enable call.
  * ---------------------------------------------------------------------------------------- */

@@ -162,10 +162,16 @@ class OracleMMDiT:
     (Linear [out,in]; x_embedder.proj.weight [out,kh,kw,in]).
     """
 
-    def __init__(self, cfg, weights: Dict[str, Tensor], prec: Optional[Prec] = None, gelu: str = "erf"):
+    def __init__(self, cfg, weights: Dict[str, Tensor], prec: Optional[Prec] = None, gelu: str = "erf", act_quant=None,
+                 guidance: Optional[float] = None):
         self.cfg = cfg
         self.w = weights
         self.P = prec or Prec()
+        # fp8 path of the MI355X build (no reference counterpart, oracle/fp8.py): fake-quantisation applied to the INPUT of every
+        # Linear of the transformer blocks (q/k/v, o_proj, fc1, fc2); the weights handed in are then the dequantised fp8 ones
+        self.aq = act_quant or (lambda x: x)
+        # FLUX.1-dev guidance strength (cfg.guidance_embed): see cache_modulation_params
+        self.guidance = guidance
         self.gelu = {"erf": gelu_erf, "tanh": gelu_tanh}[gelu]  # "erf" = the MLX path (quirk Q3)
         # timestep embedding is evaluated in config.dtype independently of the activation
         # dtype (quirk Q2); the exact oracle keeps it exact.
@@ -189,6 +195,14 @@ class OracleMMDiT:
         cfg, P = self.cfg, self.P
         B = pooled.shape[0]
         y_embed = self._mlp_embed(P.r(pooled), "y_embedder")  # [B,h]
+        if getattr(cfg, "guidance_embed", False):
+            # The reference declares guidance_in = MLPEmbedder(frequency_embed_dim -> hidden) (mmdit.py:31-36,945-955) but never
+            # reaches its call site (:219-220; model_io.py:109 runs FLUX.1-dev on the schnell preset, quirk Q7).  Restated here
+            # with the published FLUX.1-dev semantics the module tree was written for: the sinusoidal embedding of
+            # 1000 * guidance through the MLP, added to the modulation vector of every batch row and timestep.
+            g = torch.full((1,), 1000.0 * float(self.guidance if self.guidance is not None else 3.5))
+            gemb = timestep_embedding(g, cfg, self.P_embed)
+            y_embed = P.r(y_embed + self._mlp_embed(P.r(gemb), "guidance_in"))
         self._mod = {}
         for t in timesteps:
             key = float(t)
@@ -216,9 +230,10 @@ class OracleMMDiT:
         cfg, P = self.cfg, self.P
         mod = self._mod[prefix][tkey].chunk(n_mod, dim=-1)
         m = affine_transform(x, mod[0], mod[1], cfg.layer_norm_eps, P)
-        q = self._lin(m, prefix + ".attn.q_proj")
-        k = self._lin(m, prefix + ".attn.k_proj", bias=False)  # quirk Q9
-        v = self._lin(m, prefix + ".attn.v_proj")
+        mq = self.aq(m)
+        q = self._lin(mq, prefix + ".attn.q_proj")
+        k = self._lin(mq, prefix + ".attn.k_proj", bias=False)  # quirk Q9
+        v = self._lin(mq, prefix + ".attn.v_proj")
         B, S, _ = x.shape
         H, D = cfg.num_heads, cfg.head_dim
 
@@ -229,21 +244,21 @@ class OracleMMDiT:
         if cfg.use_qk_norm:
             q = rms_norm(q, self.w[prefix + ".qk_norm.q_norm.weight"], 1e-6, P)
             k = rms_norm(k, self.w[prefix + ".qk_norm.k_norm.weight"], 1e-6, P)
-        return {"q": q, "k": k, "v": v, "m": m, "mod": mod}
+        return {"q": q, "k": k, "v": v, "m": mq, "mod": mod}
 
     def _post_sdpa(self, residual, sdpa_out, inter, prefix, parallel_mlp):
         cfg, P = self.cfg, self.P
         mod = inter["mod"]
-        attn_out = self._lin(sdpa_out, prefix + ".attn.o_proj")
+        attn_out = self._lin(self.aq(sdpa_out), prefix + ".attn.o_proj")
         if parallel_mlp:
             # fc2 bias is zeroed on every call (mmdit.py:741-742, quirk Q8)
             h1 = self.gelu(self._lin(inter["m"], prefix + ".mlp.fc1"), P)
-            mlp_out = linear(h1, self.w[prefix + ".mlp.fc2.weight"], None, P)
+            mlp_out = linear(self.aq(h1), self.w[prefix + ".mlp.fc2.weight"], None, P)
             return P.r(residual + P.r(mod[2] * P.r(attn_out + mlp_out)))
         residual = P.r(residual + P.r(attn_out * mod[2]))
         m2 = affine_transform(residual, mod[3], mod[4], cfg.layer_norm_eps, P)
-        h1 = self.gelu(self._lin(m2, prefix + ".mlp.fc1"), P)
-        mlp_out = self._lin(h1, prefix + ".mlp.fc2")
+        h1 = self.gelu(self._lin(self.aq(m2), prefix + ".mlp.fc1"), P)
+        mlp_out = self._lin(self.aq(h1), prefix + ".mlp.fc2")
         return P.r(residual + P.r(mod[5] * mlp_out))
 
     def _merge(self, t):  # [B,H,S,D] -> [B,S,h]

@@ -94,10 +94,13 @@ def cfg_denoise(model: OracleMMDiT, x_t: Tensor, timestep: float, sigma: float,
 
 
 def sample_euler(model: OracleMMDiT, x: Tensor, sigmas: Tensor, conditioning: Tensor,
-                 pooled: Tensor, cfg_weight: float, act: Prec, trace: Optional[list] = None) -> Tensor:
+                 pooled: Tensor, cfg_weight: float, act: Prec, trace: Optional[list] = None,
+                 t_act: Optional[Prec] = None) -> Tensor:
     """sample_euler (mlx/__init__.py:761-788): x stays fp32; model timesteps are
-    sigma*1000 rounded to the activation dtype (quirk Q1)."""
-    timesteps = act.r(sigmas * 1000.0)
+    sigma*1000 rounded to the pipeline's activation dtype (quirk Q1; :683,770): fp16 for
+    DiffusionPipeline (:76-79), bf16 for FluxPipeline (:610-613).  ``t_act`` = that rounding when it differs
+    from ``act`` (the MI355X engine keeps bf16 activations for SD3 but rounds its timesteps to fp16)."""
+    timesteps = (t_act or act).r(sigmas * 1000.0)
     model.cache_modulation_params(pooled, timesteps)
     for i in range(len(sigmas) - 1):
         den = cfg_denoise(model, x, float(timesteps[i]), float(sigmas[i]), conditioning, cfg_weight, act)
@@ -126,7 +129,7 @@ def encode_image_to_latents(encoder, image: Tensor, seed: int) -> Tensor:
 def denoise_latents(model: OracleMMDiT, conditioning: Tensor, pooled: Tensor, num_steps: int,
                     cfg_weight: float, latent_size, seed: int, shift: float, flux: bool,
                     act: Prec, trace: Optional[list] = None, init_latent: Optional[Tensor] = None,
-                    denoise: float = 1.0) -> Tensor:
+                    denoise: float = 1.0, t_act: Optional[Prec] = None) -> Tensor:
     """DiffusionPipeline.denoise_latents (mlx/__init__.py:253-292).  ``init_latent`` = the output of
     encode_image_to_latents for img2img (image_path given), else the empty latent and denoise = 1."""
     fmt = "flux" if flux else "sd3"
@@ -140,7 +143,7 @@ def denoise_latents(model: OracleMMDiT, conditioning: Tensor, pooled: Tensor, nu
     sigmas = get_sigmas(shift, flux, num_steps)
     sigmas = sigmas[int(num_steps * (1 - denoise)):]
     noise_scaled = sigmas[0] * noise + (1.0 - sigmas[0]) * x_T  # sampler.py:41-42
-    latent = sample_euler(model, noise_scaled, sigmas, conditioning, pooled, cfg_weight, act, trace)
+    latent = sample_euler(model, noise_scaled, sigmas, conditioning, pooled, cfg_weight, act, trace, t_act)
     return process_out(latent, "flux" if flux else "sd3")
 
 

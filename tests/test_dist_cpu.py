@@ -47,6 +47,17 @@ def _worker(rank, world, port, q):
         ok = ok and len(g) == w and all(int(g[i].max()) == i for i in range(w))
     else:
         ok = ok and g is None
+    # uneven shards (3 seeds over 2 ranks -> 1 + 2 images; 1 seed -> rank 0 holds none): counts exchanged, blocks padded
+    for n_seeds in (3, 1):
+        mine = dk.shard_seeds(list(range(n_seeds)), r, w)
+        imgs = torch.stack([torch.full((4, 4, 3), 10 + s, dtype=torch.uint8) for s in mine]) if mine else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
+        g = dk.gather_images(imgs, dst=0)
+        if r == 0:
+            flat = torch.cat(g, 0)
+            ok = ok and [int(t.shape[0]) for t in g] == [len(dk.shard_seeds(list(range(n_seeds)), i, w)) for i in range(w)]
+            ok = ok and flat.shape[0] == n_seeds and [int(flat[i].max()) for i in range(n_seeds)] == [10 + s for s in range(n_seeds)]
+        else:
+            ok = ok and g is None
     seeds = dk.shard_seeds(list(range(8)), r, w)
     ok = ok and seeds == list(range(4 * r, 4 * r + 4))
     dist.barrier()
