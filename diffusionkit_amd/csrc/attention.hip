@@ -250,10 +250,11 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
   DK_REQUIRE(p.D == 128 || p.D == 64, "head_dim must be 64 or 128");
   DK_REQUIRE(p.S > 0 && p.B > 0 && p.H > 0, "empty attention");
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");
-  // automatic choice (kernel lab, profiles/r01_attention_lab.md): the VALU-lean kernel, 8 waves per
-  // workgroup for D = 128 on long sequences (K/V staging shared by 8 waves), 4 waves otherwise
-  // a score bias (text encoders) is only implemented by the lean kernel's 4-wave form
-  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 5 : 4) : g_dk_attn_mode;
+  // automatic choice (kernel lab, profiles/r01_attention_lab.md, profiles/r02_attn_bench.log): D = 128 on long sequences: the
+  // software-pipelined kernel with 8 waves per workgroup (K/V staging shared by 8 waves; +4 % over the lean kernel on the FLUX
+  // shapes); otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF against 773 / 823 for the pipelined forms).
+  // A score bias (text encoders) is only implemented by the lean kernel's 4-wave form
+  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 7 : 4) : g_dk_attn_mode;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   int rc = 0;
 #define DK_ATTN_CASE(M, NW, VAR)                                                     \
@@ -268,6 +269,8 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
     case 4: rc = dk_launch_attention2(p, 4, stream); break;
     case 5: rc = dk_launch_attention2(p, 8, stream); break;
     case 6: rc = dk_launch_attention2(p, 7, stream); break;
+    case 7: rc = dk_launch_attention3(p, 8, stream); break;  // software-pipelined kernel (attention3.hip), 8 / 4 waves
+    case 8: rc = dk_launch_attention3(p, 4, stream); break;
     default: DK_REQUIRE(false, "unknown attention variant");
   }
 #undef DK_ATTN_CASE

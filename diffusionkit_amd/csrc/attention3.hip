@@ -30,7 +30,13 @@ struct Attn3Cfg {
   static constexpr int NCH = NCHUNK / NT;    // per thread
   static constexpr int CPR = D / 8;
   static constexpr int QB = NW * 32;
-  static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2] V[2]
+  // D = 128: the Q fragments (32 registers) live in a wave-private LDS image instead of registers -- with two score tiles in
+  // flight the register file (256 per wave at 2 waves per SIMD) does not hold them without spilling.  Every lane re-reads the 16
+  // bytes it wrote, so the image is simply lane-linear per fragment ([kk][lane][16 B]: one address register + immediates,
+  // conflict-free; 8 more ds_read_b128 per tile)
+  static constexpr bool QLDS = D == 128;
+  static constexpr int Q_OFF = 4 * TILE_BYTES;
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES + (QLDS ? NW * 32 * ROWB : 0);  // K[2] V[2] (+ Q per wave)
   static_assert(NCHUNK % NT == 0, "tile chunks must divide over the workgroup");
 };
 
@@ -141,6 +147,13 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   for (int par = 0; par < 2; ++par)
     vr_off[par] = (unsigned)(x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8);
 
+  if (C::QLDS) {
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk)
+      *(__attribute__((address_space(3))) bf16x8*)(lds + C::Q_OFF + wave * (32 * C::ROWB) + lane * 16 + kk * 1024) = qf[kk];
+  }
+  const unsigned q_lds = C::Q_OFF + wave * (32 * C::ROWB) + lane * 16;  // (same wave writes and reads: program order + lgkmcnt suffice)
+
   u32x4 kreg[C::NCH], vreg[C::NCH];
   const int ntiles = (S + 63) / 64;
   // one operand's 64-key tile jt -> registers through a buffer descriptor: one 32-bit lane offset per chunk (shared by K and V)
@@ -170,8 +183,9 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   _Pragma("unroll") for (int kk = 0; kk < D / 16; ++kk) {                                                                                      \
     const bf16x8 k0_ = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + (kr_base ^ (unsigned)(kk << 5)));    \
     const bf16x8 k1_ = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + 32 * C::ROWB + (kr_base ^ (unsigned)(kk << 5)));  \
-    A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0_, qf[kk], A0, 0, 0, 0);                                                                    \
-    A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1_, qf[kk], A1, 0, 0, 0);                                                                    \
+    const bf16x8 q_ = C::QLDS ? *(const __attribute__((address_space(3))) bf16x8*)(lds + q_lds + kk * 1024) : qf[kk];                           \
+    A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0_, q_, A0, 0, 0, 0);                                                                        \
+    A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1_, q_, A1, 0, 0, 0);                                                                        \
   }
 // scores of keys beyond the sequence end (tail tile JT) -> -1e30
 #define DK3_MASK(JT, A0, A1)                                              \

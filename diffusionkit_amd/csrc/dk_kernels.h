@@ -47,6 +47,7 @@ int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream);  //
 extern int g_dk_gemm_mode;
 extern int g_dk_v2_sched;
 extern int g_dk_v3_split;  // gemm256v3.hip: remainder-wave K split (-1 auto, 0 off, 1 whenever possible)
+extern int g_dk_v3_mf;     // gemm256v3.hip: wave-tile height in 16-row fragments (-1 auto, 8 = 256-row tiles, 7 = 224-row tiles)
 // stream-K form (persistent grid, fp32 slabs + flags in a caller-owned workspace whose last 4 KiB
 // -- the flag region -- must be zero before the first launch; kernels leave it zero)
 size_t dk_streamk_workspace_bytes();
@@ -135,6 +136,7 @@ struct AttnParams {
 };
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
+int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream);  // attention3.hip (two tiles in flight per wave; no score bias)
 
 // ---- text-conditioning kernels (text_ops.hip) ---------------------------------------------------
 int dk_launch_embedding(const bf16_t* table, const int* ids, const bf16_t* pos, int pos_rows, bf16_t* out, float* out_f32, int n, int dim,

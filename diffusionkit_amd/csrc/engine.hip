@@ -32,6 +32,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "gemm_sched") == 0) { g_dk_v2_sched = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
+  if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
@@ -252,10 +253,14 @@ struct Carver {
 };
 
 // the lean attention kernel (modes -1, 4, 5, 6) can normalise / rotate the queries in its Q load; the first-generation one cannot
-static int fuse_q() { return g_dk_fuse_q && (g_dk_attn_mode < 0 || g_dk_attn_mode >= 4) ? 1 : 0; }
+static int fuse_q() { return g_dk_fuse_q && (g_dk_attn_mode < 0 || g_dk_attn_mode >= 4) ? 1 : 0; }  // (modes 7 / 8: attention3 has the fused Q load too)
 
-// workspace handed to every GEMM the engines build (set by dk_mmdit_prepare; one engine per process and device)
-static void* g_linear_ws = nullptr;
+// Split workspace (fp32 slabs + flags) handed to the GEMMs an engine call builds: every dk_mmdit_* entry point sets it to ITS
+// engine's region (carved from that engine's workspace) before it enqueues anything and all launches of the call are
+// enqueued before it returns, so two engines -- on one host thread in turn, or on two threads / streams at once
+// (thread_local) -- never share a flag region.  A single engine must not be driven from two streams concurrently (its
+// activations live in one workspace anyway).
+static thread_local void* g_linear_ws = nullptr;
 
 static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                                 bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,

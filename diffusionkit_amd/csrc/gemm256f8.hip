@@ -21,9 +21,11 @@
 // behaviour carry over -- and ONE MFMA per (16 x 16) fragment pair consumes it whole: 32 MFMAs of 2 x 16 x 16 x 128 flop per
 // wave and K-tile, each twice as long as a bf16 16x16x32 one, i.e. the same MFMA time per K-tile for twice the K depth.
 //
-// Operand fragment: lane (l15 = lane & 15, q = lane >> 4) holds row l15, K-elements [32 q, 32 q + 32) = two ds_read_b128.
-// To keep the bf16 kernel's conflict-free read pattern (16-byte chunk (4 j + q) ^ swz(row) for read j), the DMA puts global
-// chunk 2 q + j at that LDS position: a rotation of the 3-bit chunk index on the SOURCE address, full 128-byte lines still.
+// Operand fragment (pinned on hardware by scripts/fp8_probe.hip, profiles/r02_fp8_probe.log): lane (l15 = lane & 15,
+// q = lane >> 4) holds row l15; its first four registers are K-elements [16 q, 16 q + 16), its last four [64 + 16 q, 64 + 16 q + 16)
+// -- the instruction is two K = 64 halves -- and the scale register byte of lane (l15, g) is the E8M0 scale of row l15, K-elements
+// [32 g, 32 g + 32).  Read j of a fragment therefore takes the 16-byte chunk 4 j + q of the row: exactly the bf16 kernel's
+// conflict-free pattern (chunk (4 j + q) ^ swz(row)), and the 8 scale bytes a lane loads per K-tile are those of block q.
 //
 // K-tile schedule (4 steps of 8 MFMAs; A fragments in two sets of two, W fragments in ONE set of four that is reloaded
 // fragment by fragment behind its last use):
@@ -93,12 +95,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const int tn = (tl % tpg) / gsz;
   const int m0 = tm * T256, n0 = tn * T256;
 
-  // DMA sources.  LDS position t (after the row swizzle) of a row takes global chunk rot(t) = 2 (t & 3) + (t >> 2)
+  // DMA sources: LDS position (lane & 7) of a row takes global chunk (lane & 7) ^ swz(row) (the read side XORs it back)
   unsigned la[2][2], lw[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int t = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane & 7) ^ swz(row), row = wave * 16 + j * 8 + srow
-    const int chunk = ((t & 3) << 1) | (t >> 2);
+    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane & 7) ^ swz(row), row = wave * 16 + j * 8 + srow
     lw[j] = (unsigned)srow * (unsigned)p.ldw + chunk * 16;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -256,17 +257,20 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   {
     i32x4 wlo[4], whi[4], a0lo[2], a0hi[2], a1lo[2], a1hi[2];
     // prologue: scales of K-tile 0, K-tile 0 completely, and the first half of K-tile 1 (the loop issues the rest in S0)
+    // (the asm load's destination must not be read -- not even copied -- before its wait: no branch-dependent statement names it,
+    //  so that no merge of two definitions makes the compiler copy the register while the load is in flight; a first build did)
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_cur) : "v"(sa_ptr) : "memory");
 #pragma unroll
     for (int gidx = 0; gidx < 8; ++gidx) issue_piece(0, gidx);
     if (nk > 1) {
 #pragma unroll
       for (int gidx = 0; gidx < 4; ++gidx) issue_piece(1, gidx);
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(sa_cur)::"memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa_cur)::"memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    sa_nxt = sa_cur;  // (behind the wait: the copy must not read the register before the load has landed)
+    asm volatile("" : "+v"(sa_cur));  // from here on the scales of K-tile 0 are there in either case
+    sa_nxt = u32x2{0u, 0u};
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not be live across

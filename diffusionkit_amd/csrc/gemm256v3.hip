@@ -26,6 +26,12 @@
 // 16-byte store per lane and row; bias / GELU (erfc polynomial) / SiLU / gate * x + residual on the way.
 // Remainder waves can be cut along K (SplitArgs, plan_split): finisher + producer pieces through fp32 slabs.
 //
+// Tile height: template parameter MF = 16-row fragments per wave along m, 8 (256-row tiles) or 7 (224-row tiles).  The hot
+// shapes have M = 4352 / 4608 / 8192 rows and N / 256 = 12 .. 48 column tiles: with 256-row tiles the last round of the 256 CUs is
+// 20 % empty (N = 3072: 204 tiles, one round), with 224-row tiles the same work is 240 / 252 tiles of 7/8 the size -- one round
+// of 0.875 tile-times instead of 1.0.  The launcher takes the height that minimises rounds x height (dk_tune_set
+// ("gemm_mf", 7 | 8) forces one).  The LDS image keeps its two 128-row A slots; a 224-row tile uses 112 rows of each.
+//
 // C / D layout of the swapped-operand MFMA (A-operand = W fragment, B-operand = activation fragment):
 // lane holds output row m = mf*16 + (lane & 15), columns n = nf*16 + 4*(lane >> 4) + {0..3}.
 #include <cstring>
@@ -107,7 +113,12 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int base, int count) {
   return start + ((bid - base) >> 3);
 }
 
+template <int MF>
 __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, SplitArgs sp) {
+  static_assert(MF == 8 || MF == 7, "wave tile: 8 or 7 fragments of 16 rows");
+  constexpr int BM = 32 * MF;     // tile rows (two wave rows)
+  constexpr int HROWS = 16 * MF;  // rows of one wave row = rows used of a 128-row LDS slot
+  constexpr int NHI = MF - 4;     // fragments of the second ("hi") m-group of a wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
   const int tid = threadIdx.x;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const bool second = tile >= tiles_a;
   const GemmParams& p = second ? pb : pa;
   const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
-  const int nbm = (p.M + T256 - 1) / T256, nbn = p.N / T256;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / T256;
 
   // ---- lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), chunk 4*kk + q ----
   unsigned offk[2];
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const int gsz = min(nbm - first_m, GROUP);
   const int tm = first_m + (tl % tpg) % gsz;
   const int tn = (tl % tpg) / gsz;
-  const int m0 = tm * T256, n0 = tn * T256;
+  const int m0 = tm * BM, n0 = tn * T256;
 
   // DMA sources: A rows through the segment map per lane (32-bit byte offsets from p.A; rows beyond M - 1 re-read
   // the last row, their results are never stored), W rows from a tile-uniform base + lane part
@@ -171,7 +182,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const int m = min(m0 + hh * 128 + wave * 16 + j * 8 + srow, p.M - 1);
+      // (MF = 7: wave 7's rows lie beyond the 112 rows a wave row uses -- it fetches duplicates of other rows into LDS rows
+      //  nobody reads, so that every wave issues the same 8 pieces per K-tile)
+      const int m = min(m0 + hh * HROWS + wave * 16 + j * 8 + srow, p.M - 1);
       const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
       la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
     }
@@ -199,11 +212,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     for (int gidx = 0; gidx < 8; ++gidx) issue_piece(i, gidx);
   };
 
-  f32x4 acc[4][8];  // [nf][mf]
+  f32x4 acc[4][MF];  // [nf][mf]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < MF; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_LDS_RD(xf##SET[0], aA_, 8192);              \
     DK_LDS_RD(xf##SET[1], aA_, 10240);             \
     DK_LDS_RD(xf##SET[2], aA_, 12288);             \
-    DK_LDS_RD(xf##SET[3], aA_, 14336);             \
+    if (NHI > 3) DK_LDS_RD(xf##SET[3], aA_, 14336); \
   } while (0)
 // the wait in front of the tile barrier: own fragment reads and own DMA pieces of the next K-tile.  (lab: 256 = the DMA
 // pieces get one more K-tile to land -- results are wrong, the timing is that of a ring with twice the window)
@@ -246,18 +259,26 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
   } while (0)
 #define DK_WAIT4(N, V) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]))
+// everything but the NHI hi-fragment reads issued last has landed
+#define DK_WAIT8_HI(V, U)                        \
+  do {                                           \
+    if constexpr (NHI == 4) DK_WAIT8(4, V, U);   \
+    else DK_WAIT8(3, V, U);                      \
+  } while (0)
 #define DK_WAIT8(N, V, U)                  \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" \
                : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]))
 // 16 MFMAs acc[nf][MB + mf] += W[nf] . A[mf], with NG DMA pieces (TILE, G0 ..) in front of slots PH, PH+4, ... when ON
-#define DK_MMG(WSET, ASET, MB, TILE, G0, NG, PH, ON) DK_MMGR(WSET, ASET, MB, TILE, G0, NG, PH, ON, 0, 16)
-#define DK_MMGR(WSET, ASET, MB, TILE, G0, NG, PH, ON, E0, E1)                                                     \
+// (NM = m-fragments of the group: 4, or NHI for the hi group; a step is 4 * NM MFMAs, MFMA e_ = (nf = e_ / NM, mf = e_ % NM); the
+//  pieces sit NM slots apart so that four of them fit any step)
+#define DK_MMG(WSET, ASET, MB, NM, TILE, G0, NG, PH, ON) DK_MMGR(WSET, ASET, MB, NM, TILE, G0, NG, PH, ON, 0, 4 * (NM))
+#define DK_MMGR(WSET, ASET, MB, NM, TILE, G0, NG, PH, ON, E0, E1)                                                 \
   do {                                                                                                            \
     _Pragma("unroll") for (int e_ = (E0); e_ < (E1); ++e_) {                                                           \
-      if (!(DK_V3_ABL & 1) && (NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) % DK_V3_STR) == 0 && ((e_ - (PH)) / DK_V3_STR) < (NG)) \
-        issue_piece((TILE), (G0) + ((e_ - (PH)) / DK_V3_STR));                                                    \
-      acc[e_ >> 2][(MB) + (e_ & 3)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##WSET[e_ >> 2], xf##ASET[e_ & 3], \
-                                                                              acc[e_ >> 2][(MB) + (e_ & 3)], 0, 0, 0); \
+      if (!(DK_V3_ABL & 1) && (NG) > 0 && (ON) && e_ >= (PH) && ((e_ - (PH)) % (NM)) == 0 && ((e_ - (PH)) / (NM)) < (NG)) \
+        issue_piece((TILE), (G0) + ((e_ - (PH)) / (NM)));                                                         \
+      acc[e_ / (NM)][(MB) + (e_ % (NM))] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##WSET[e_ / (NM)], xf##ASET[e_ % (NM)], \
+                                                                                   acc[e_ / (NM)][(MB) + (e_ % (NM))], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                          \
     }                                                                                                             \
   } while (0)
@@ -269,21 +290,21 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     constexpr bool in_loop = true;                                                                               \
     const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
     DK_RDA_HI(1, bo, 0);                                                                                         \
-    DK_WAIT8(4, wf0, xf0);                                                                                       \
-    DK_MMG(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1);                                                         \
+    DK_WAIT8_HI(wf0, xf0);                                                                                       \
+    DK_MMG(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1);                                                      \
     DK_RDW(1, bo, 1);                                                                                            \
     DK_RDA_LO(0, bo, 1);                                                                                         \
     DK_WAIT4(8, xf1);                                                                                            \
-    DK_MMG(0, 1, 4, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, ON1);                                              \
+    DK_MMG(0, 1, 4, NHI, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, ON1);                                         \
     DK_RDA_HI(1, bo, 1);                                                                                         \
-    DK_WAIT8(4, wf1, xf0);                                                                                       \
-    DK_MMG(1, 0, 0, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, ON1);                                   \
+    DK_WAIT8_HI(wf1, xf0);                                                                                       \
+    DK_MMG(1, 0, 0, 4, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, ON1);                                \
     DK_TILE_WAIT(xf1);                                                                                           \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
     DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */        \
     DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */        \
-    DK_MMG(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2);                                                                \
+    DK_MMG(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2);                                                           \
   }
 // The same K-tile for the second wave of each SIMD with its fragment reads behind MFMA slot R of every step instead of
 // in front of it, so that the two waves of a SIMD do not run their read / wait sections at the same time (+1.5-2 %).
@@ -291,26 +312,27 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   {                                                                                                              \
     constexpr bool in_loop = true;                                                                               \
     const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
+    constexpr int RH = (R) * NHI / 4; /* the same relative slot inside a hi step of 4 * NHI MFMAs */            \
     DK_WAIT8(0, wf0, xf0);                                                                                       \
-    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, 0, R);                                                  \
+    DK_MMGR(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, 0, R);                                               \
     DK_RDA_HI(1, bo, 0);                                                                                         \
-    DK_MMGR(0, 0, 0, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, R, 16);                                                 \
+    DK_MMGR(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, R, 16);                                              \
     DK_WAIT4(0, xf1);                                                                                            \
-    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, 0, R);                                                               \
+    DK_MMGR(0, 1, 4, NHI, i + 1, 0, 0, 0, false, 0, RH);                                                         \
     DK_RDW(1, bo, 1);                                                                                            \
     DK_RDA_LO(0, bo, 1);                                                                                         \
-    DK_MMGR(0, 1, 4, i + 1, 0, 0, 0, false, R, 16);                                                              \
+    DK_MMGR(0, 1, 4, NHI, i + 1, 0, 0, 0, false, RH, 4 * NHI);                                                   \
     DK_WAIT8(0, wf1, xf0);                                                                                       \
-    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, 0, R);                                                               \
+    DK_MMGR(1, 0, 0, 4, i + 1, 0, 0, 0, false, 0, R);                                                            \
     DK_RDA_HI(1, bo, 1);                                                                                         \
-    DK_MMGR(1, 0, 0, i + 1, 0, 0, 0, false, R, 16);                                                              \
+    DK_MMGR(1, 0, 0, 4, i + 1, 0, 0, 0, false, R, 16);                                                           \
     DK_TILE_WAIT(xf1);                                                                                           \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
-    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2, 0, R);                                                         \
+    DK_MMGR(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2, 0, RH);                                                   \
     DK_RDW(0, bo ^ KT_BYTES, 0);                                                                                 \
     DK_RDA_LO(0, bo ^ KT_BYTES, 0);                                                                              \
-    DK_MMGR(1, 1, 4, i + 2, 0, DK_V3_N3, PH, ON2, R, 16);                                                        \
+    DK_MMGR(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2, RH, 4 * NHI);                                             \
   }
 // all K-tiles of this workgroup: branch-free steady state, then the two tiles that issue less.  The fragments in flight
 // at a section boundary are waited for there (an inline-asm load must not be in flight across a compiler-visible merge).
@@ -365,6 +387,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_WAIT4
 #undef DK_TILE_WAIT
 #undef DK_WAIT8
+#undef DK_WAIT8_HI
 #undef DK_MMG
 #undef DK_MMGR
 #undef DK_ITER
@@ -381,12 +404,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const bool has_res = epi == DK_EPI_GATE_RES || epi == DK_EPI_RES;
   // a tile that lies inside one row segment of every map and inside M evaluates the maps once (scalar unit);
   // otherwise each lane walks its rows through the maps (fast == false)
-  auto inside = [&](int len) { return m0 / len == (m0 + T256 - 1) / len; };
-  const bool fast = m0 + T256 <= p.M && inside(p.c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
+  auto inside = [&](int len) { return m0 / len == (m0 + BM - 1) / len; };
+  const bool fast = m0 + BM <= p.M && inside(p.c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
                     (epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
-  const int mrow0 = m0 + wm * 128;  // first GEMM row of this wave's block
-  const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
-  const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128 : 0;
+  const int mrow0 = m0 + wm * HROWS;  // first GEMM row of this wave's block
+  const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * HROWS;
+  const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * HROWS : 0;
   const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
   const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
   // read-back: a lane takes 8 consecutive columns (two 16-byte chunks) of one row, 4 lanes a 32-column row of the
@@ -430,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 8; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         const int row = mf * 16 + l15;
         *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
       }
@@ -453,8 +476,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
 #pragma unroll 4
-      for (int itr = 0; itr < 8; ++itr) {
-        const int row = itr * 16 + rrow;  // row inside the wave's 128-row block
+      for (int itr = 0; itr < MF; ++itr) {
+        const int row = itr * 16 + rrow;  // row inside the wave's block of HROWS rows
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
         bool valid = true;
         if (!FAST) {
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         f32x4 a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
         f32x4 a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
         if (piece >= 0) {  // split tile
-          const size_t slab_idx = (size_t)(wm * 128 + row) * 256 + wn * 64 + ni * 32 + rc2 * 4;
+          const size_t slab_idx = (size_t)(wm * HROWS + row) * 256 + wn * 64 + ni * 32 + rc2 * 4;
           if (piece >= 1) {
             if (!(DK_V3_ABL & 8)) {  // (lab: 8 = producers do not store)
               v3_store_sc1_b128(my_slab + slab_idx, a0);
@@ -597,16 +620,41 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
   return SplitPlan{tiles - T, T, S, ks};
 }
 
-int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream) {
+// dk_tune_set("gemm_mf", v): wave-tile height in 16-row fragments; -1 (default) = the height with the fewest rounds x height, 8 / 7 forced
+int g_dk_v3_mf = -1;
+
+// Tile height for a launch: rounds of the CUs x rows per tile, over both problems of a grouped launch (same N).
+static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
+  if (g_dk_v3_mf == 7 || g_dk_v3_mf == 8) return g_dk_v3_mf;
+  long best_cost = 0;
+  int best = 8;
+  for (int mf = 8; mf >= 7; --mf) {
+    const int bm = 32 * mf;
+    long tiles = (long)((p.M + bm - 1) / bm) * (p.N / T256);
+    if (p2) tiles += (long)((p2->M + bm - 1) / bm) * (p2->N / T256);
+    const long cost = ((tiles + n_cu - 1) / n_cu) * bm;
+    if (mf == 8 || cost < best_cost) { best_cost = cost; best = mf; }
+  }
+  return best;
+}
+
+// `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)
+int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*tiles_a*/, int tiles_b_in, hipStream_t stream) {
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     DK_CHECK_HIP(hipGetDevice(&dev));
     DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
+  const bool two = tiles_b_in > 0;
+  const int mf = pick_mf(p, two ? &pb : nullptr, n_cu);
+  const int bm = 32 * mf;
+  const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / T256);
+  const int tiles_b = two ? ((pb.M + bm - 1) / bm) * (pb.N / T256) : 0;
   const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_streamk_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0;
   const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
   SplitArgs sp;
@@ -618,7 +666,10 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles
     sp.error_word = sp.flags + 512;
   }
   const int grid = pl.n_dp + pl.n_rem * pl.S;
-  hipLaunchKernelGGL(dk_gemm256v3_kernel, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+  if (mf == 8)
+    hipLaunchKernelGGL(dk_gemm256v3_kernel<8>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+  else
+    hipLaunchKernelGGL(dk_gemm256v3_kernel<7>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
   return 0;
 }
 
@@ -631,12 +682,10 @@ int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t s
                    (p.n_split == 0 || p2->epi2 == p.epi2),
                "grouped GEMM: N, K, epilogue must match");
   }
-  const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
-  const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
-  const int rc = dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, tiles_a, tiles_b, stream);
+  const int rc = dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, 0, p2 ? 1 : 0, stream);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return rc;

@@ -1,0 +1,37 @@
+"""Attention kernel A/B (lab): dk_attention_bf16 under dk_tune_set("attn", mode) on the bench shapes, interleaved rounds in one
+process (guide rule 24).  modes: 5 = dk_attn2 8 waves (round-1 default for D = 128), 4 = dk_attn2 4 waves, 7 / 8 = dk_attn3 8 / 4 waves."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from diffusionkit_amd import ops
+
+dev = torch.device("cuda", 0)
+shapes = [("flux B1 S4352 D128", 1, 24, 4352, 128), ("flux-dev B1 S4608 D128", 1, 24, 4608, 128), ("sd3 B2 S4685 D64", 2, 24, 4096 + 589, 64),
+          ("flux B4", 4, 24, 4352, 128)]
+modes = [int(m) for m in (sys.argv[1:] or ["5", "7", "4", "8"])]
+if os.environ.get("ATTN_SHAPES"):
+    shapes = shapes[:int(os.environ["ATTN_SHAPES"])]
+for name, B, H, S, D in shapes:
+    qkv = (torch.randn(B, S, 3 * H * D, device=dev) * 1.0).to(torch.bfloat16)
+    flops = 4.0 * B * H * S * S * D
+    best = {m: 1e9 for m in modes}
+    outs = {}
+    for rnd in range(5):
+        for m in modes:
+            ops.tune("attn", m)
+            for _ in range(2):
+                y = ops.attention(qkv, H, D)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                y = ops.attention(qkv, H, D)
+            e1.record()
+            torch.cuda.synchronize()
+            best[m] = min(best[m], e0.elapsed_time(e1) / 10)
+            outs[m] = y
+    ops.tune("attn", -1)
+    ref = outs[modes[0]].float()
+    print(name, "  ".join(f"m{m}: {best[m] * 1e3:7.1f} us {flops / best[m] / 1e9:7.1f} TF (max|d| vs m{modes[0]} {float((outs[m].float() - ref).abs().max()):.3g})" for m in modes), flush=True)

@@ -2,10 +2,11 @@
 // block-scaled MFMA and its fp8 conversion, and measures the instruction's issue rate.
 //   hipcc --offload-arch=gfx950 -O3 scripts/fp8_probe.hip -o build_lab/fp8_probe && build_lab/fp8_probe
 //
-// 1. v_mfma_scale_f32_16x16x128_f8f6f4 with both operands e4m3:
-//    operand lane l holds row (l & 15), the 32 K-elements [32 * (l >> 4), +32) in byte order; its scale register
-//    byte (selected by op_sel) is the E8M0 scale of exactly that (row, 32-block); C/D: lane l holds column l & 15,
-//    rows 4 * (l >> 4) + {0..3}.
+// 1. v_mfma_scale_f32_16x16x128_f8f6f4 with both operands e4m3.  Test 1 / 2 state the FIRST hypothesis -- operand lane l holds row
+//    (l & 15), the 32 K-elements [32 * (l >> 4), +32), and its scale byte scales exactly those -- and FAIL on hardware; section 1b
+//    maps which register positions a lane's scale governs.  Result (profiles/r02_fp8_probe.log): lane (r, q) holds
+//    K [16 q, 16 q + 16) in registers 0-3 and K [64 + 16 q, +16) in registers 4-7; the scale byte of lane (r, g) scales row r,
+//    K [32 g, 32 g + 32).  Test 4 states that and passes.  C/D: lane l holds column l & 15, rows 4 * (l >> 4) + {0..3}.
 // 2. v_cvt_pk_fp8_f32: round-to-nearest-even OCP e4m3, what happens above 448.
 // 3. rate: 256 workgroups x 8 waves, 8 independent accumulators.
 #include <hip/hip_runtime.h>
@@ -59,11 +60,13 @@ __global__ void mfma_once(const uint8_t* A, const uint8_t* B, const int* sa, con
   const int l = threadIdx.x, row = l & 15, kb = l >> 4;
   v8i a, b;
   for (int j = 0; j < 8; ++j) {
-    a[j] = *(const int*)(A + row * 128 + kb * 32 + 4 * j);
-    b[j] = *(const int*)(B + row * 128 + kb * 32 + 4 * j);
+    // OPSEL 4 = the layout found on hardware: registers 0-3 <- K [16 kb, +16), registers 4-7 <- K [64 + 16 kb, +16)
+    const int off = OPSEL == 4 ? (j < 4 ? kb * 16 + 4 * j : 64 + kb * 16 + 4 * (j - 4)) : kb * 32 + 4 * j;
+    a[j] = *(const int*)(A + row * 128 + off);
+    b[j] = *(const int*)(B + row * 128 + off);
   }
   v4f acc = {0.f, 0.f, 0.f, 0.f};
-  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, OPSEL, sa[l], OPSEL, sb[l]);
+  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, OPSEL & 3, sa[l], OPSEL & 3, sb[l]);
   for (int r = 0; r < 4; ++r) D[(4 * kb + r) * 16 + row] = acc[r];  // D[i][j]: i = A row, j = B row
 }
 
@@ -125,12 +128,13 @@ int main() {
   CK(hipMalloc(&dA, A.size())); CK(hipMalloc(&dB, B.size())); CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256)); CK(hipMalloc(&dD, 1024));
   CK(hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice));
   CK(hipMemcpy(dB, B.data(), B.size(), hipMemcpyHostToDevice));
-  for (int test = 0; test < 4; ++test) {
+  for (int test = 0; test < 5; ++test) {
     // test 0: all scales 1 (byte 0); 1: random per-lane scales in byte 0; 2: random scales in byte 2, garbage elsewhere, op_sel 2;
     // 3: scale registers vary only with the row (lanes l, l+16, .. share it) -- a cross-check of the (row, block) association
     std::vector<int> sa(64), sb(64);
     std::vector<int> ea(64), eb(64);
     for (int l = 0; l < 64; ++l) {
+      // (test 4: random per-lane scales like test 1, checked against the layout section 1b found)
       ea[l] = test == 0 ? 127 : test == 3 ? 120 + (l & 15) : 121 + rand() % 12;
       eb[l] = test == 0 ? 127 : test == 3 ? 127 : 121 + rand() % 12;
       if (test == 2) {
@@ -144,6 +148,7 @@ int main() {
     CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice));
     CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
     if (test == 2) hipLaunchKernelGGL(mfma_once<2>, dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+    else if (test == 4) hipLaunchKernelGGL(mfma_once<4>, dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
     else hipLaunchKernelGGL(mfma_once<0>, dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
     CK(hipDeviceSynchronize());
     std::vector<float> D(256);
@@ -158,7 +163,7 @@ int main() {
         worst = fmax(worst, fabs(acc - D[i * 16 + j]));
         ref_max = fmax(ref_max, fabs(acc));
       }
-    printf("mfma_scale test %d: max |D - ref| = %.3e (|ref| max %.3e)  %s\n", test, worst, ref_max, worst <= 1e-4 * ref_max ? "PASS" : "FAIL");
+    printf("mfma_scale test %d: max |D - ref| = %.3e (|ref| max %.3e)  %s\n", test, worst, ref_max, worst <= 1e-3 * ref_max ? "PASS" : "FAIL");  // (the MFMA's internal sum is not a full fp32 chain: ~1e-4 relative)
   }
   // ---- 1b. which data positions does lane L's scale govern?  A = ones, B = ones at register positions (lane group qb, byte half h)
   //          only, scale of lane L = 2^3, all others 2^0: D[i][j] = 16 * 8 if L governs (row i, qb, h), else 16

@@ -153,9 +153,10 @@ def test_mmdit_fp8_tiny(dev, B):
     e_h, e_e = rel_l2(res["fq_fp32"], out), rel_l2(res["fq_fp32"], res["fq_emu"])
     assert e_h <= 2.0 * e_e + 2e-3, (e_h, e_e)
     assert psnr(res["fq_fp32"], out) > 35.0
-    # what fp8 costs against the un-quantised model (reported, loosely bounded)
-    print(f"fp8 tiny B={B}: PSNR vs fp32 un-quantised oracle {psnr(res['fp32'], out):.1f} dB (fake-quant oracle itself: {psnr(res['fp32'], res['fq_fp32']):.1f} dB)")
-    assert psnr(res["fp32"], out) > psnr(res["fp32"], res["fq_fp32"]) - 3.0
+    # what fp8 costs against the un-quantised model (reported; bounded by what the bf16-emulating fake-quant oracle reaches)
+    print(f"fp8 tiny B={B}: PSNR vs fp32 un-quantised oracle {psnr(res['fp32'], out):.1f} dB (fake-quant oracle: fp32 arithmetic "
+          f"{psnr(res['fp32'], res['fq_fp32']):.1f} dB, bf16-emulating {psnr(res['fp32'], res['fq_emu']):.1f} dB)")
+    assert psnr(res["fp32"], out) > psnr(res["fp32"], res["fq_emu"]) - 3.0
 
 
 def test_mmdit_fp8_rejects_unaligned_token_counts(dev):

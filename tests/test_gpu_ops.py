@@ -158,9 +158,10 @@ def test_gemm_streamk_joint_stream_in_place(dev):
         assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP, mode
 
 
+@pytest.mark.parametrize("mf", [8, 7])
 @pytest.mark.parametrize("epi", ["bias", "gate_res", "res"])
 @pytest.mark.parametrize("B,S_t,S_i", [(2, 589, 64), (3, 77, 11), (1, 300, 0)])
-def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi):
+def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi, mf):
     """The 16x16x32-MFMA 256^2 kernel on the text stream of a joint [B, S_t + S_i] buffer: M = B * S_t is not
     a multiple of 256 and (B > 1) tiles straddle the row segments of every map (A, C, residual, gate), so
     the per-lane row walk of the tail and the clamped DMA rows are exercised; rows of the other stream and
@@ -187,13 +188,34 @@ def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi):
         ref[:, :S_t] = X[:, :S_t] + bf16r(gate[:, None, N:] * o)
     try:
         ops.tune("gemm", 9)
+        ops.tune("gemm_mf", mf)  # 256-row and 224-row tiles
         ops.gemm_desc_call(**kw)
     finally:
         ops.tune("gemm", -1)
+        ops.tune("gemm_mf", -1)
     got = Xd.float().cpu()
     assert torch.equal(got[:, S_t:], X[:, S_t:])  # rows of the other stream untouched
     assert rel_l2(ref[:, :S_t], got[:, :S_t]) < TOL_SINGLE_OP
     assert max_abs(ref[:, :S_t], got[:, :S_t]) < 0.02 * float(ref.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(4352, 3072, 3072), (224, 256, 64), (449, 512, 192), (4608, 256, 128)])
+def test_gemm_v3_tile_heights_agree(dev, M, N, K):
+    """224-row tiles (gemm_mf 7) against 256-row tiles (8): the same fp32 accumulation order per output element, so the results
+    are bit-identical; M exactly one / two tiles, one row over, and the FLUX shapes the automatic choice switches on."""
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=60), randn(N, K, seed=61, scale=0.05), randn(N, seed=62, scale=0.1)
+    outs = {}
+    for mf in (8, 7, -1):
+        try:
+            ops.tune("gemm", 9)
+            ops.tune("gemm_mf", mf)
+            outs[mf] = ops.linear(g(x, dev), g(w, dev), g(b, dev))
+        finally:
+            ops.tune("gemm", -1)
+            ops.tune("gemm_mf", -1)
+    assert rel_l2(bf16r(x @ w.t() + b), outs[8].float()) < TOL_SINGLE_OP
+    assert torch.equal(outs[8], outs[7]) and torch.equal(outs[8], outs[-1])
 
 
 # ---- conv ---------------------------------------------------------------------------------------
@@ -219,7 +241,8 @@ def test_conv3x3(dev, B, H, W, C, O, ups, res):
                                        (1178, 512, 384, "bias"),         # ragged M, 10 tiles
                                        (3328, 2560, 256, "gelu"),        # 130 tiles > half the CUs: finisher + 1 producer
                                        (4352, 3072, 512, "gate_res")])   # 204 tiles, 4 producer pieces in turn per spare CU
-def test_gemm_v3_remainder_split(dev, M, N, K, epi):
+@pytest.mark.parametrize("mf", [8, 7])
+def test_gemm_v3_remainder_split(dev, M, N, K, epi, mf):
     """dk_tune_set("gemm_split", 1): the tiles beyond the last full wave of the CUs are cut along K into a
     finisher piece and producer pieces (fp32 slabs + flags in the caller's workspace).  Same results as
     the unsplit kernel up to the fp32 summation order; the flag region must be left zero."""
@@ -237,6 +260,7 @@ def test_gemm_v3_remainder_split(dev, M, N, K, epi):
         ref = acc
     try:
         ops.tune("gemm", 9)
+        ops.tune("gemm_mf", mf)
         ops.tune("gemm_split", 1)
         y = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
         ops.tune("gemm_split", 0)
@@ -244,6 +268,7 @@ def test_gemm_v3_remainder_split(dev, M, N, K, epi):
     finally:
         ops.tune("gemm", -1)
         ops.tune("gemm_split", -1)
+        ops.tune("gemm_mf", -1)
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
     assert max_abs(y0.float(), y.float()) <= 0.02 * float(ref.abs().max()) + 1e-2  # a bf16 ulp where the summation order differs
     assert float((y0.float() != y.float()).float().mean()) < 0.02
@@ -295,8 +320,9 @@ def test_attention(dev, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 3, 1088, 128),
+                                     (2, 2, 589 + 64, 64)])
 def test_attention_kernel_variants(dev, mode, B, H, S, D):
     """Every attention kernel variant behind dk_tune_set("attn", mode) (4 / 8 waves, interleaved score
     chains, the VALU-lean kernel with the deferred rescale) against the oracle; ragged tail tile."""
@@ -326,7 +352,7 @@ def test_attention_spiked_key_forces_rescale(dev):
     p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
     ref = (p @ v[0])[None]
     assert float(p[7, 250]) > 0.9
-    for mode in (0, 4, 5):  # always-rescale kernel and the deferred-rescale kernels (threshold path)
+    for mode in (0, 4, 5, 7, 8):  # always-rescale kernel and the deferred-rescale kernels (threshold path; 7 / 8: pipelined kernel)
         try:
             ops.tune("attn", mode)
             y = ops.attention(g(qkv, dev), H, D)
