@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) weights + MX-fp8 activations on the block-scaled fp8 MFMA (BASELINE configs[3])")
     ap.add_argument("--guidance-embed", action="store_true",
                     help="FLUX.1-dev guidance embedding on (config FLUX_DEV); off = the reference's behaviour, which runs dev on the schnell preset")
+    ap.add_argument("--overlap-decode", action="store_true",
+                    help="decode image i on a side stream while image i+1 is denoised (DiffusionPipeline.decode_async); the default, and the "
+                         "headline, is the reference's order: denoise, then decode, image by image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -229,17 +232,25 @@ def main():
 
     denoise_ms, vae_ms = [], []
 
+    pending = []
+
     def one_image(seed):
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         lat, _ = pipe.denoise_latents(cond, pooled, num_steps=num_steps, cfg_weight=cfg_weight, latent_size=latent,
                                       seed=seed if B == 1 else [seed * B + b for b in range(B)])
         e1.record()
-        _, u8, _ = pipe.decoder.decode(lat)
+        if args.overlap_decode:
+            pending.append(pipe.decode_async(lat))  # waited for in barrier(): every image is decoded inside the timed region
+            u8 = None
+        else:
+            _, u8, _ = pipe.decoder.decode(lat)
         e2.record()
         return u8, (e0, e1, e2)
 
     def barrier():
+        while pending:
+            pending.pop().result()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -337,7 +348,8 @@ def main():
             "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
             "config": {"workload": f"{args.workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
                                    f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8"
-                                   + (", guidance embedding on" if cfg.guidance_embed else ""),
+                                   + (", guidance embedding on" if cfg.guidance_embed else "")
+                                   + (", decode of image i overlapped with the denoising of image i+1 (side stream)" if args.overlap_decode else ""),
                        "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
             "denoise_ms_per_step": round(float(np.mean(denoise_ms)) / num_steps, 2),
             "vae_decode_ms": round(float(np.mean(vae_ms)), 2),

@@ -623,19 +623,22 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
 // dk_tune_set("gemm_mf", v): wave-tile height in 16-row fragments; -1 (default) = the height with the fewest rounds x height, 8 / 7 forced
 int g_dk_v3_mf = -1;
 
-// Tile height for a launch: rounds of the CUs x rows per tile, over both problems of a grouped launch (same N).
+// Tile height for a launch.  Model: rounds of the CUs x rows per tile, over both problems of a grouped launch (same N).  Measured
+// (profiles/r02_gemm_tile_height.log): on the FLUX shapes 224-row tiles save 2.7 % of the GEMM time -- far less than the 12.5 %
+// the model promises, because a K-tile runs slower the more CUs are busy (the chip is power / fabric bound) -- and on
+// the short-K SD3 shapes the 15 % extra tiles (each with its fixed prologue + tail) cost more than the fuller round gives back.
+// So: 224-row tiles only for long reductions, and only when the model predicts at least 10 %.
 static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
   if (g_dk_v3_mf == 7 || g_dk_v3_mf == 8) return g_dk_v3_mf;
-  long best_cost = 0;
-  int best = 8;
-  for (int mf = 8; mf >= 7; --mf) {
+  if (p.K < 2048) return 8;
+  long cost[2];
+  for (int mf = 7; mf <= 8; ++mf) {
     const int bm = 32 * mf;
     long tiles = (long)((p.M + bm - 1) / bm) * (p.N / T256);
     if (p2) tiles += (long)((p2->M + bm - 1) / bm) * (p2->N / T256);
-    const long cost = ((tiles + n_cu - 1) / n_cu) * bm;
-    if (mf == 8 || cost < best_cost) { best_cost = cost; best = mf; }
+    cost[mf - 7] = ((tiles + n_cu - 1) / n_cu) * bm;
   }
-  return best;
+  return cost[0] * 10 <= cost[1] * 9 ? 7 : 8;
 }
 
 // `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)

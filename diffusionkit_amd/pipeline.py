@@ -398,6 +398,35 @@ class DiffusionPipeline:
         img, _, _ = self.decoder.decode(x_t)
         return img
 
+    def decode_async(self, latents: Tensor) -> "PendingDecode":
+        """Serving helper with no reference counterpart (the reference decodes inline, mlx/__init__.py:497-530): enqueue the VAE
+        decode of ``latents`` on the pipeline's side stream, behind an event on the current stream, and return at once -- the
+        denoising of the NEXT image then overlaps this one's decode (the decoder's GroupNorm passes and 128-channel convs are
+        HBM-bound, the MMDiT GEMMs MFMA-bound).  ``PendingDecode.result()`` hands back (image_f32, image_u8) once the current
+        stream has been made to wait for the decode.  Same kernels, same results as ``decoder.decode``."""
+        if not hasattr(self, "_decode_stream"):
+            self._decode_stream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._decode_stream):
+            self._decode_stream.wait_event(ready)
+            latents.record_stream(self._decode_stream)
+            img, u8, _ = self.decoder.decode(latents)
+            done = torch.cuda.Event()
+            done.record(self._decode_stream)
+        return PendingDecode(img, u8, done, self.device)
+
+
+class PendingDecode:
+    """A VAE decode in flight on the pipeline's side stream (DiffusionPipeline.decode_async)."""
+
+    def __init__(self, img, u8, done, device):
+        self._img, self._u8, self._done, self._device = img, u8, done, device
+
+    def result(self):
+        torch.cuda.current_stream(self._device).wait_event(self._done)
+        return self._img, self._u8
+
 
 class FluxPipeline(DiffusionPipeline):
     _IS_FLUX = True

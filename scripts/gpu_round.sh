@@ -36,7 +36,7 @@ if has pmc; then
     find $OUT/pmc_$TAGC -name "*kernel_trace.csv" -size +30M -delete
   done
   python scripts/pmc_traffic.py $OUT > $OUT/pmc_traffic.log 2>&1; tail -n 12 $OUT/pmc_traffic.log
-  { python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES gemm256v3; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES attn2; } > $OUT/pmc_sq.log 2>&1
+  { python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES gemm256v3; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES dk_attn; } > $OUT/pmc_sq.log 2>&1
   rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES  # raw CSVs exceed the 64 MiB pull limit
 fi
 ls -la $OUT

@@ -456,3 +456,22 @@ def test_sd3_pipeline_text_lengths_and_cfg(dev):
         assert img.size == (96, 64) and len(log["denoising"]["iter_time"]) == 2
         img0, _ = pipe.generate_image("a photo", num_steps=2, cfg_weight=0.0, latent_size=(8, 12), seed=5, verbose=False)
         assert img0.size == (96, 64) and np.asarray(img0).tobytes() != np.asarray(img).tobytes()  # guidance changes the image
+
+
+def test_decode_async_equals_inline_decode(dev):
+    """DiffusionPipeline.decode_async (VAE decode on the side stream, overlapped with the next image's denoising in a serving loop):
+    bit-identical images to the inline decode, also with a denoise enqueued in between."""
+    from diffusionkit_amd.pipeline import FluxPipeline
+    cfg = tiny_flux()
+    pipe = FluxPipeline(w16=True, a16=True, mmdit_config=cfg, vae_config=tiny_vae(), device=dev, text_len=16)
+    text, pooled = randn(1, 16, cfg.token_level_text_embed_dim, seed=7).to(dev, BF), randn(1, cfg.pooled_text_embed_dim, seed=8).to(dev, BF)
+    lats = [pipe.denoise_latents(text, pooled, num_steps=2, latent_size=(8, 8), seed=s)[0] for s in (1, 2)]
+    want = [pipe.decoder.decode(l)[1].clone() for l in lats]
+    pend = []
+    for s, l in zip((1, 2), lats):
+        pend.append(pipe.decode_async(l))
+        pipe.denoise_latents(text, pooled, num_steps=2, latent_size=(8, 8), seed=s + 10)  # work on the main stream meanwhile
+    for p, w in zip(pend, want):
+        img, u8 = p.result()
+        torch.cuda.synchronize()
+        assert torch.equal(u8, w) and img.shape == (1, 64, 64, 3)
