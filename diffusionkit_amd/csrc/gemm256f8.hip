@@ -39,6 +39,9 @@
 
 #include "dk_kernels.h"
 
+#ifndef DK_F8_ABL
+#define DK_F8_ABL 0  // lab only (timing ablations, results wrong): 1 no scale loads in the K loop, 2 no DMA in it, 4 no fragment reads in it
+#endif
 #ifndef DK_F8_SAFE
 #define DK_F8_SAFE 0  // lab / debugging: every LDS wait is lgkmcnt(0)
 #endif
@@ -141,7 +144,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-#define F8_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define F8_RD(DST, ADDR, OFF)                                                                                        \
+  do {                                                                                                               \
+    if (!(DK_F8_ABL & 4) || !in_loop) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR));       \
+  } while (0)
 // the two m-fragments (MFA, MFA + 1) of a set: 4 reads
 #define F8_RDA(SET, BUFOFF, OFFA, OFFB)                 \
   do {                                                  \
@@ -180,18 +186,19 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 // DMA piece G of K-tile TILE in front of MFMA slot SLOT of a step, when this wave group's phase PH puts it there
 #define F8_PIECE(ON, TILE, G0, SLOT, PH)                                                    \
   do {                                                                                      \
-    if ((ON) && (SLOT) >= (PH) && (((SLOT) - (PH)) & 1) == 0 && (((SLOT) - (PH)) >> 1) < 4) \
+    if ((ON) && !(DK_F8_ABL & 2) && (SLOT) >= (PH) && (((SLOT) - (PH)) & 1) == 0 && (((SLOT) - (PH)) >> 1) < 4) \
       issue_piece((TILE), (G0) + (((SLOT) - (PH)) >> 1));                                   \
   } while (0)
 // One K-tile.  ON1 / ON2 (compile-time): whether the DMA pieces (and scales) of K-tile i+1 (second half) / i+2 (first half)
 // are issued -- false only in the last two K-tiles, so that the steady-state loop carries no branches around them.
 #define F8_ITER(PH, ON1, ON2)                                                                                       \
   {                                                                                                                 \
+    constexpr bool in_loop = true;                                                                                  \
     const unsigned bo = (i & 1) * KT_BYTES;                                                                         \
     /* ---- S0: (n 0..3) x (m 0,1) ---- */                                                                         \
     F8_WAIT6(6, a0lo[0], a0hi[0], a0lo[1], a0hi[1], wlo[0], whi[0]);                                                \
     F8_RDA(a1, bo, 4096, 6144);                                                                                     \
-    if (ON1) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_nxt) : "v"(sa_ptr + (size_t)(i + 1) * sa_step) : "memory"); \
+    if ((ON1) && !(DK_F8_ABL & 1)) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_nxt) : "v"(sa_ptr + (size_t)(i + 1) * sa_step) : "memory"); \
     F8_PIECE(ON1, i + 1, 4, 0, PH); F8_MM(0, a0, 0, 0);                                                             \
     F8_PIECE(ON1, i + 1, 4, 1, PH); F8_MM(0, a0, 1, 1);                                                             \
     F8_WAIT2(8, wlo[1], whi[1]);                                                                                    \
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     asm volatile("" ::: "memory");
     // (the first fragment reads sit INSIDE the branches: an inline-asm load that is still in flight must not be live across
     //  a compiler-visible branch)
+    constexpr bool in_loop = false;
     if (wm == 0) {
       F8_RDA(a0, 0u, 0, 2048);
       F8_RDW(0, 0u, 0); F8_RDW(1, 0u, 2048); F8_RDW(2, 0u, 4096); F8_RDW(3, 0u, 6144);
@@ -352,7 +360,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
         if (has_res) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
         if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
-#pragma unroll 4
+      // MX-fp8 output on a tile-uniform row map: a lane's eight rows (itr) are the eight 16-row fragments of its 128-row block, and
+      // their scale bytes are the eight consecutive bytes of ONE word of the side array (dk_mx_scale_index: byte (r / 16) % 8) --
+      // collected in two registers over the (fully unrolled) loop, stored once per lane quad and 32-column half
+      unsigned sc_lo = 0u, sc_hi = 0u;
+#pragma unroll
       for (int itr = 0; itr < 8; ++itr) {
         const int row = itr * 16 + rrow;  // row inside the wave's 128-row block
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
@@ -403,10 +415,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           for (int e = 0; e < 8; ++e) vv[e] = round_bf16(vv[e]);
           unsigned e8;
           const uint2 q8 = dk_mx8_quantize8(vv, e8);
-          if (FAST || valid) {
-            *(uint2*)((unsigned char*)Cb + crow * (size_t)ldcb + ocol) = q8;
-            if ((lane & 3) == 0)
-              p.SC[dk_mx_scale_index((unsigned)crow + (unsigned)p.c_row0, (unsigned)(p.sc_kb0 + (ocol >> 5)), (unsigned)p.sc_nblk)] = (unsigned char)e8;
+          if (FAST || valid) *(uint2*)((unsigned char*)Cb + crow * (size_t)ldcb + ocol) = q8;
+          if (FAST) {
+            if (itr < 4) sc_lo |= e8 << (8 * (itr & 3));
+            else sc_hi |= e8 << (8 * (itr & 3));
+          } else if (valid && (lane & 3) == 0) {
+            p.SC[dk_mx_scale_index((unsigned)crow + (unsigned)p.c_row0, (unsigned)(p.sc_kb0 + (ocol >> 5)), (unsigned)p.sc_nblk)] = (unsigned char)e8;
           }
         } else {
           uint4 o4;
@@ -416,6 +430,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           o4.w = pack2bf(vv[6], vv[7]);
           if (FAST || valid) *(uint4*)((bf16_t*)Cb + crow * (size_t)ldcb + ocol) = o4;
         }
+      }
+      if (FAST && out_mx8 && (lane & 3) == 0) {
+        // rows physC0 + c_row0 + rrow + 16 * {0..7}: one aligned 128-row block (the launcher checks the alignment), bytes 0..7
+        const unsigned r0 = (unsigned)physC0 + (unsigned)p.c_row0 + (unsigned)rrow;
+        const unsigned kb = (unsigned)(p.sc_kb0 + (ocol >> 5));
+        *(uint2*)(p.SC + dk_mx_scale_index(r0, kb, (unsigned)p.sc_nblk)) = make_uint2(sc_lo, sc_hi);
       }
     };
     if (fast)
@@ -440,7 +460,9 @@ bool dk_gemm256f8_eligible(const GemmF8Params& p) {
   auto al = [](const void* q, int a) { return ((uintptr_t)q & (uintptr_t)(a - 1)) == 0; };
   if (p.c_mx8 ? (p.ldc % 8 != 0 || !al(p.C, 8)) : (p.ldc % 8 != 0 || !al(p.C, 16))) return false;
   if (p.n_split > 0 && (p.c2_mx8 ? (p.ldc2 % 8 != 0 || !al(p.C2, 8)) : (p.ldc2 % 8 != 0 || !al(p.C2, 16)))) return false;
-  if ((p.c_mx8 || (p.n_split > 0 && p.c2_mx8)) && (p.SC == nullptr || p.sc_nblk <= 0)) return false;
+  if ((p.c_mx8 || (p.n_split > 0 && p.c2_mx8)) &&
+      (p.SC == nullptr || p.sc_nblk <= 0 || p.c_seg_len % 128 != 0 || p.c_seg_stride % 128 != 0 || p.c_row0 % 128 != 0))
+    return false;  // (the tail stores a 128-row block's eight scale bytes as one word)
   if (!al(p.res, 16) || !al(p.bias, 16) || !al(p.gate, 16) || !al(p.wscale, 16) || (p.gate != nullptr && p.gate_stride % 8 != 0)) return false;
   // 32-bit byte offsets on the DMA side
   const size_t a_rows = (size_t)((p.M - 1) / p.a_seg_len) * p.a_seg_stride + (size_t)((p.M - 1) % p.a_seg_len) + 1;
