@@ -49,8 +49,12 @@
 #define T256 256
 #define BKB 128                      // bytes (= fp8 elements) of a row per K-tile
 #define HALF_BYTES (128 * BKB)       // 128 rows
-#define KT_BYTES (4 * HALF_BYTES)    // A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255
-#define LDS_BYTES (2 * KT_BYTES)
+#define OP_BYTES (2 * HALF_BYTES)    // one operand of one K-tile: rows 0-127, rows 128-255
+// LDS ring: two slots of the activation operand, THREE of the weight operand (all 160 KiB): weights stream from HBM (every
+// block of the model has its own), activations come out of L2 / Infinity Cache -- so the weight pieces of K-tile i+2 are issued
+// 1.75 K-tiles ahead of their first read, the activation pieces 1.0 ahead (the in-order vmcnt lets the newest four stay in flight)
+#define W_BASE (2 * OP_BYTES)
+#define LDS_BYTES (5 * OP_BYTES)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) char lds_char;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #pragma unroll
   for (int j = 0; j < 2; ++j) offk[j] = (unsigned)(l15 * 128 + (((j * 4 + q) ^ (l15 >> 1)) << 4));
   const unsigned sA = wm * HALF_BYTES;
-  const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
+  const unsigned sW = W_BASE + (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * 128;
 
   const int srow = lane >> 3;
   const int GROUP = 4;
@@ -116,15 +120,16 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const size_t w128 = (size_t)128 * p.ldw, w8 = (size_t)8 * p.ldw;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
-  auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
-    const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
-    const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
-    if (op == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, (int)la[hh][j],
-                                               i * BKB, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, (int)lw[j],
-                                               (int)(hh * w128 + j * w8) + i * BKB, 0, 0);
+  // the four DMA instructions (k: half, j) of one operand of K-tile i; `slot` = byte offset of the ring slot it goes to
+  auto issue_a = [&](int i, int k) {
+    const int hh = k & 1, j = k >> 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + (i & 1) * OP_BYTES + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024),
+                                             16, (int)la[hh][j], i * BKB, 0, 0);
+  };
+  auto issue_w = [&](int i, unsigned slot, int k) {
+    const int hh = k & 1, j = k >> 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + W_BASE + slot + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024), 16,
+                                             (int)lw[j], (int)(hh * w128 + j * w8) + i * BKB, 0, 0);
   };
 
   // E8M0 scales of this wave's 128 A rows for one K-tile: 8 bytes per lane (byte mf = row mf * 16 + l15, block q), one
@@ -172,9 +177,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #define F8_WAIT4(N, A, B, C_, D_) asm volatile("s_waitcnt lgkmcnt(" F8_CNT(N) ")" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_))
 #define F8_WAIT6(N, A, B, C_, D_, E_, F_) \
   asm volatile("s_waitcnt lgkmcnt(" F8_CNT(N) ")" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_), "+v"(E_), "+v"(F_))
-// the wait in front of the tile barrier: own fragment reads, own DMA pieces and the scale load of the next K-tile
-#define F8_TILE_WAIT(A, B, C_, D_, S_) \
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_), "+v"(S_)::"memory")
+// the wait in front of the tile barrier: own fragment reads, own DMA pieces of the next K-tile and its scale load; the four
+// weight pieces of K-tile i+2 (the newest four memory operations) stay in flight
+#define F8_TILE_WAIT(KEEP, A, B, C_, D_, S_) \
+  asm volatile("s_waitcnt vmcnt(" #KEEP ") lgkmcnt(0)" : "+v"(A), "+v"(B), "+v"(C_), "+v"(D_), "+v"(S_)::"memory")
 #define F8_FRAG(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
 // one MFMA: acc[NF][MF] += W[NF] . A(SET)[AI]; scale of the activation rows = byte (MF & 3) of sa_cur[MF >> 2]
 #define F8_MM(NF, SET, AI, MF)                                                                                              \
@@ -183,33 +189,38 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
                                                                    acc[NF][MF], 0, 0, 0, 0x7F7F7F7F, (MF) & 3, (int)sa_cur[(MF) >> 2]); \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
   } while (0)
-// DMA piece G of K-tile TILE in front of MFMA slot SLOT of a step, when this wave group's phase PH puts it there
-#define F8_PIECE(ON, TILE, G0, SLOT, PH)                                                    \
-  do {                                                                                      \
-    if ((ON) && !(DK_F8_ABL & 2) && (SLOT) >= (PH) && (((SLOT) - (PH)) & 1) == 0 && (((SLOT) - (PH)) >> 1) < 4) \
-      issue_piece((TILE), (G0) + (((SLOT) - (PH)) >> 1));                                   \
+// a DMA piece in front of MFMA slot SLOT of a step, when this wave group's phase PH puts it there (W: weight pieces, A: activation)
+#define F8_PIECE_ON(ON, SLOT, PH) ((ON) && !(DK_F8_ABL & 2) && (SLOT) >= (PH) && (((SLOT) - (PH)) & 1) == 0 && (((SLOT) - (PH)) >> 1) < 4)
+#define F8_PIECE_W(ON, TILE, SLOT, PH)                                             \
+  do {                                                                             \
+    if (F8_PIECE_ON(ON, SLOT, PH)) issue_w((TILE), wo_nn, ((SLOT) - (PH)) >> 1);   \
   } while (0)
-// One K-tile.  ON1 / ON2 (compile-time): whether the DMA pieces (and scales) of K-tile i+1 (second half) / i+2 (first half)
-// are issued -- false only in the last two K-tiles, so that the steady-state loop carries no branches around them.
+#define F8_PIECE_A(ON, TILE, SLOT, PH)                                             \
+  do {                                                                             \
+    if (F8_PIECE_ON(ON, SLOT, PH)) issue_a((TILE), ((SLOT) - (PH)) >> 1);          \
+  } while (0)
+// One K-tile.  ON1 / ON2 (compile-time): whether the scales of K-tile i+1 / the DMA pieces of K-tile i+2 (weights in S0,
+// activations in S3 -- in that program order, see F8_TILE_WAIT) are issued -- false only in the last two K-tiles, so that the
+// steady-state loop carries no branches around them.  wo_cur / wo_nxt / wo_nn: ring slots of the weights of K-tiles i, i+1, i+2.
 #define F8_ITER(PH, ON1, ON2)                                                                                       \
   {                                                                                                                 \
     constexpr bool in_loop = true;                                                                                  \
-    const unsigned bo = (i & 1) * KT_BYTES;                                                                         \
+    const unsigned bo = (i & 1) * OP_BYTES;                                                                         \
     /* ---- S0: (n 0..3) x (m 0,1) ---- */                                                                         \
     F8_WAIT6(6, a0lo[0], a0hi[0], a0lo[1], a0hi[1], wlo[0], whi[0]);                                                \
     F8_RDA(a1, bo, 4096, 6144);                                                                                     \
     if ((ON1) && !(DK_F8_ABL & 1)) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_nxt) : "v"(sa_ptr + (size_t)(i + 1) * sa_step) : "memory"); \
-    F8_PIECE(ON1, i + 1, 4, 0, PH); F8_MM(0, a0, 0, 0);                                                             \
-    F8_PIECE(ON1, i + 1, 4, 1, PH); F8_MM(0, a0, 1, 1);                                                             \
+    F8_PIECE_W(ON2, i + 2, 0, PH); F8_MM(0, a0, 0, 0);                                                             \
+    F8_PIECE_W(ON2, i + 2, 1, PH); F8_MM(0, a0, 1, 1);                                                             \
     F8_WAIT2(8, wlo[1], whi[1]);                                                                                    \
-    F8_PIECE(ON1, i + 1, 4, 2, PH); F8_MM(1, a0, 0, 0);                                                             \
-    F8_PIECE(ON1, i + 1, 4, 3, PH); F8_MM(1, a0, 1, 1);                                                             \
+    F8_PIECE_W(ON2, i + 2, 2, PH); F8_MM(1, a0, 0, 0);                                                             \
+    F8_PIECE_W(ON2, i + 2, 3, PH); F8_MM(1, a0, 1, 1);                                                             \
     F8_WAIT2(6, wlo[2], whi[2]);                                                                                    \
-    F8_PIECE(ON1, i + 1, 4, 4, PH); F8_MM(2, a0, 0, 0);                                                             \
-    F8_PIECE(ON1, i + 1, 4, 5, PH); F8_MM(2, a0, 1, 1);                                                             \
+    F8_PIECE_W(ON2, i + 2, 4, PH); F8_MM(2, a0, 0, 0);                                                             \
+    F8_PIECE_W(ON2, i + 2, 5, PH); F8_MM(2, a0, 1, 1);                                                             \
     F8_WAIT2(4, wlo[3], whi[3]);                                                                                    \
-    F8_PIECE(ON1, i + 1, 4, 6, PH); F8_MM(3, a0, 0, 0);                                                             \
-    F8_PIECE(ON1, i + 1, 4, 7, PH); F8_MM(3, a0, 1, 1);                                                             \
+    F8_PIECE_W(ON2, i + 2, 6, PH); F8_MM(3, a0, 0, 0);                                                             \
+    F8_PIECE_W(ON2, i + 2, 7, PH); F8_MM(3, a0, 1, 1);                                                             \
     /* ---- S1: x (m 2,3) ---- */                                                                                   \
     F8_RDA(a0, bo, 8192, 10240);                                                                                    \
     F8_WAIT4(4, a1lo[0], a1hi[0], a1lo[1], a1hi[1]);                                                                \
@@ -220,24 +231,26 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     F8_WAIT4(4, a0lo[0], a0hi[0], a0lo[1], a0hi[1]);                                                                \
     F8_MM(0, a0, 0, 4); F8_MM(0, a0, 1, 5); F8_MM(1, a0, 0, 4); F8_MM(1, a0, 1, 5);                                 \
     F8_MM(2, a0, 0, 4); F8_MM(2, a0, 1, 5); F8_MM(3, a0, 0, 4); F8_MM(3, a0, 1, 5);                                 \
-    F8_TILE_WAIT(a1lo[0], a1hi[0], a1lo[1], a1hi[1], sa_nxt);                                                       \
+    if (ON2) F8_TILE_WAIT(4, a1lo[0], a1hi[0], a1lo[1], a1hi[1], sa_nxt);                                           \
+    else F8_TILE_WAIT(0, a1lo[0], a1hi[0], a1lo[1], a1hi[1], sa_nxt);                                               \
     __builtin_amdgcn_s_barrier();                                                                                   \
     asm volatile("" ::: "memory");                                                                                  \
     /* ---- S3: x (m 6,7); next tile's first A set and, fragment by fragment, its W set ---- */                     \
-    F8_RDA(a0, bo ^ KT_BYTES, 0, 2048);  /* unconditional: after the last tile these read stale ring data nobody uses */ \
-    F8_PIECE(ON2, i + 2, 0, 0, PH); F8_MM(0, a1, 0, 6);                                                             \
-    F8_PIECE(ON2, i + 2, 0, 1, PH); F8_MM(0, a1, 1, 7);                                                             \
-    F8_RDW(0, bo ^ KT_BYTES, 0);                                                                                    \
-    F8_PIECE(ON2, i + 2, 0, 2, PH); F8_MM(1, a1, 0, 6);                                                             \
-    F8_PIECE(ON2, i + 2, 0, 3, PH); F8_MM(1, a1, 1, 7);                                                             \
-    F8_RDW(1, bo ^ KT_BYTES, 2048);                                                                                 \
-    F8_PIECE(ON2, i + 2, 0, 4, PH); F8_MM(2, a1, 0, 6);                                                             \
-    F8_PIECE(ON2, i + 2, 0, 5, PH); F8_MM(2, a1, 1, 7);                                                             \
-    F8_RDW(2, bo ^ KT_BYTES, 4096);                                                                                 \
-    F8_PIECE(ON2, i + 2, 0, 6, PH); F8_MM(3, a1, 0, 6);                                                             \
-    F8_PIECE(ON2, i + 2, 0, 7, PH); F8_MM(3, a1, 1, 7);                                                             \
-    F8_RDW(3, bo ^ KT_BYTES, 6144);                                                                                 \
+    F8_RDA(a0, bo ^ OP_BYTES, 0, 2048);  /* unconditional: after the last tile these read stale ring data nobody uses */ \
+    F8_PIECE_A(ON2, i + 2, 0, PH); F8_MM(0, a1, 0, 6);                                                             \
+    F8_PIECE_A(ON2, i + 2, 1, PH); F8_MM(0, a1, 1, 7);                                                             \
+    F8_RDW(0, wo_nxt, 0);                                                                                       \
+    F8_PIECE_A(ON2, i + 2, 2, PH); F8_MM(1, a1, 0, 6);                                                             \
+    F8_PIECE_A(ON2, i + 2, 3, PH); F8_MM(1, a1, 1, 7);                                                             \
+    F8_RDW(1, wo_nxt, 2048);                                                                                    \
+    F8_PIECE_A(ON2, i + 2, 4, PH); F8_MM(2, a1, 0, 6);                                                             \
+    F8_PIECE_A(ON2, i + 2, 5, PH); F8_MM(2, a1, 1, 7);                                                             \
+    F8_RDW(2, wo_nxt, 4096);                                                                                    \
+    F8_PIECE_A(ON2, i + 2, 6, PH); F8_MM(3, a1, 0, 6);                                                             \
+    F8_PIECE_A(ON2, i + 2, 7, PH); F8_MM(3, a1, 1, 7);                                                             \
+    F8_RDW(3, wo_nxt, 6144);                                                                                    \
     sa_cur = sa_nxt;                                                                                                \
+    { const unsigned t_ = wo_cur; wo_cur = wo_nxt; wo_nxt = wo_nn; wo_nn = t_; }                                    \
   }
 // everything in flight at a section boundary is waited for there (an inline-asm load must not be live across a
 // compiler-visible merge)
@@ -263,16 +276,22 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 
   {
     i32x4 wlo[4], whi[4], a0lo[2], a0hi[2], a1lo[2], a1hi[2];
-    // prologue: scales of K-tile 0, K-tile 0 completely, and the first half of K-tile 1 (the loop issues the rest in S0)
+    // prologue: scales of K-tile 0, K-tile 0 completely, then K-tile 1 (the loop's first wait lets only its own four weight
+    // pieces, of K-tile 2, stay in flight)
     // (the asm load's destination must not be read -- not even copied -- before its wait: no branch-dependent statement names it,
     //  so that no merge of two definitions makes the compiler copy the register while the load is in flight; a first build did)
+    unsigned wo_cur = 0u, wo_nxt = OP_BYTES, wo_nn = 2u * OP_BYTES;
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sa_cur) : "v"(sa_ptr) : "memory");
 #pragma unroll
-    for (int gidx = 0; gidx < 8; ++gidx) issue_piece(0, gidx);
+    for (int k = 0; k < 4; ++k) issue_w(0, wo_cur, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue_a(0, k);
     if (nk > 1) {
 #pragma unroll
-      for (int gidx = 0; gidx < 4; ++gidx) issue_piece(1, gidx);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      for (int k = 0; k < 4; ++k) issue_a(1, k);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) issue_w(1, wo_nxt, k);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -285,11 +304,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     constexpr bool in_loop = false;
     if (wm == 0) {
       F8_RDA(a0, 0u, 0, 2048);
-      F8_RDW(0, 0u, 0); F8_RDW(1, 0u, 2048); F8_RDW(2, 0u, 4096); F8_RDW(3, 0u, 6144);
+      F8_RDW(0, wo_cur, 0); F8_RDW(1, wo_cur, 2048); F8_RDW(2, wo_cur, 4096); F8_RDW(3, wo_cur, 6144);
       F8_DRIVE(0)
     } else {
       F8_RDA(a0, 0u, 0, 2048);
-      F8_RDW(0, 0u, 0); F8_RDW(1, 0u, 2048); F8_RDW(2, 0u, 4096); F8_RDW(3, 0u, 6144);
+      F8_RDW(0, wo_cur, 0); F8_RDW(1, wo_cur, 2048); F8_RDW(2, wo_cur, 4096); F8_RDW(3, wo_cur, 6144);
       F8_DRIVE(1)
     }
   }
@@ -301,7 +320,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #undef F8_WAIT6
 #undef F8_TILE_WAIT
 #undef F8_MM
-#undef F8_PIECE
+#undef F8_PIECE_ON
+#undef F8_PIECE_W
+#undef F8_PIECE_A
 #undef F8_ITER
 #undef F8_DRAIN
 #undef F8_DRIVE

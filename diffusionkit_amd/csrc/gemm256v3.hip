@@ -42,7 +42,7 @@
 #ifndef DK_V3_ABL
 #define DK_V3_ABL 0  // lab only (scripts/build_lab.sh ABL=n), bit mask: 1 no DMA inside the K loop, 2 no fragment reads inside it, 4 no tile
                      // barrier, 8 producers do not store, 16 finishers neither wait nor read, 32 no C stores, 64 no tail (run-time false),
-                     // 128 every K-tile's DMA re-reads K-tile 0 (same bytes into the LDS, all of them L2 hits), 256 see DK_TILE_WAIT
+                     // 128 every K-tile's DMA re-reads K-tile 0 (same bytes into the LDS, all of them L2 hits)
 #endif
 
 // placement of the 4 DMA pieces inside a 16-MFMA step: in front of MFMA slots PH, PH + STR, ... (PH0 / PH1 for the
@@ -61,19 +61,18 @@
 #ifndef DK_V3_SKEW_R
 #define DK_V3_SKEW_R 8  // MFMA slot of a step behind which the skewed wave group issues its fragment reads
 #endif
-// pieces per step, in issue order: the step behind the tile barrier (S3), then S0, S1, S2 of the next K-tile
-#ifndef DK_V3_N3
-#define DK_V3_N3 4
-#define DK_V3_N0 4
-#define DK_V3_N1 0
-#define DK_V3_N2 0
-#endif
 
 #define T256 256
 #define BK 64
 #define HALF_BYTES (128 * BK * 2)
-#define KT_BYTES (4 * HALF_BYTES)
-#define LDS_BYTES (2 * KT_BYTES)
+#define OP_BYTES (2 * HALF_BYTES)  // one operand of one K-tile: rows 0-127, rows 128-255
+// LDS ring: two slots of the activation operand, THREE of the weight operand (all 160 KiB).  Weights stream from HBM (every
+// block of the model has its own, 5-38 GB per step in total), activations come out of L2 / Infinity Cache: the four weight
+// pieces of K-tile i+2 are issued in the first step of K-tile i, 1.75 K-tiles ahead of their first read (a 2-slot ring gave
+// them 0.5-1.0), the activation pieces behind the tile barrier, 1.0 ahead; the in-order vmcnt lets the newest four -- the
+// weight pieces -- stay in flight across the barrier.  Cold-weight launches: within 1-6 % of warm ones (2-slot ring: 10-24 %).
+#define W_BASE (2 * OP_BYTES)
+#define LDS_BYTES (5 * OP_BYTES)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) offk[kk] = (unsigned)(l15 * 128 + (((kk * 4 + q) ^ (l15 >> 1)) << 4));
   const unsigned sA = wm * HALF_BYTES;
-  const unsigned sW = (2 + (wn >> 1)) * HALF_BYTES + (wn & 1) * 64 * 128;
+  const unsigned sW = W_BASE + (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * 128;
 
   const int srow = lane >> 3;
   const int GROUP = 4;
@@ -197,20 +196,19 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   // per-lane address and no VALU per piece
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
-  auto issue_piece = [&](int i, int gidx) {  // one of the 8 DMA instructions of K-tile i: (operand, half, j)
-    const int op = gidx & 1, hh = (gidx >> 1) & 1, j = gidx >> 2;
-    const unsigned dst0 = (i & 1) * KT_BYTES + (wave * 16) * 128;
-    if (op == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + dst0 + hh * HALF_BYTES + j * 1024), 16, (int)la[hh][j],
-                                               ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
+  // ring slots (byte offsets from W_BASE) of the weights of K-tiles i, i+1, i+2 of the loop below
+  unsigned wo_cur = 0u, wo_nxt = OP_BYTES, wo_nn = 2u * OP_BYTES;
+  // one of the 8 DMA instructions of K-tile i: gidx 0..3 the activation pieces (half, j), 4..7 the weight pieces into slot `wslot`
+  auto issue_piece_to = [&](int i, int gidx, unsigned wslot) {
+    const int hh = gidx & 1, j = (gidx >> 1) & 1;
+    if (gidx < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + (i & 1) * OP_BYTES + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024),
+                                               16, (int)la[hh][j], ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + dst0 + (2 + hh) * HALF_BYTES + j * 1024), 16, (int)lw[j],
-                                               (int)(hh * w128 + j * w8) + ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)((lds_char*)0 + W_BASE + wslot + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024),
+                                               16, (int)lw[j], (int)(hh * w128 + j * w8) + ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
   };
-  auto issue_tile = [&](int i) {
-#pragma unroll
-    for (int gidx = 0; gidx < 8; ++gidx) issue_piece(i, gidx);
-  };
+  auto issue_piece = [&](int i, int gidx) { issue_piece_to(i, gidx, wo_nn); };  // the loop only ever issues K-tile i+2
 
   f32x4 acc[4][MF];  // [nf][mf]
 #pragma unroll
@@ -249,12 +247,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     DK_LDS_RD(xf##SET[2], aA_, 12288);             \
     if (NHI > 3) DK_LDS_RD(xf##SET[3], aA_, 14336); \
   } while (0)
-// the wait in front of the tile barrier: own fragment reads and own DMA pieces of the next K-tile.  (lab: 256 = the DMA
-// pieces get one more K-tile to land -- results are wrong, the timing is that of a ring with twice the window)
-#define DK_TILE_WAIT(V)                                                                                                  \
+// the wait in front of the tile barrier: own fragment reads and own DMA pieces of the next K-tile; the four weight pieces of
+// K-tile i+2 (issued last) stay in flight when there are any (KEEP)
+#define DK_TILE_WAIT(V, KEEP)                                                                                            \
   do {                                                                                                                   \
-    if (DK_V3_ABL & 256)                                                                                                 \
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
+    if (KEEP)                                                                                                            \
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
     else                                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3])::"memory");          \
   } while (0)
@@ -282,60 +280,69 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       __builtin_amdgcn_sched_barrier(0);                                                                          \
     }                                                                                                             \
   } while (0)
-// One K-tile for the wave group that reads its fragments in FRONT of every 16-MFMA step.  ON1 / ON2 (compile-time):
-// whether the DMA pieces of K-tile i+1 (second part) / i+2 (first part) are issued -- false only in the last two
-// K-tiles, so that the steady-state loop carries no branches around the pieces.
+// One K-tile for the wave group that reads its fragments in FRONT of every 16-MFMA step.  ON2 (compile-time): whether the
+// DMA pieces of K-tile i+2 are issued (weights in the first step, activations behind the barrier -- in that program order,
+// see DK_TILE_WAIT) -- false only in the last two K-tiles, so that the steady-state loop carries no branches around the pieces.
 #define DK_ITER(PH, ON1, ON2)                                                                                    \
   {                                                                                                              \
     constexpr bool in_loop = true;                                                                               \
-    const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
+    const unsigned bo = (i & 1) * OP_BYTES;                                                                      \
     DK_RDA_HI(1, bo, 0);                                                                                         \
     DK_WAIT8_HI(wf0, xf0);                                                                                       \
-    DK_MMG(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1);                                                      \
-    DK_RDW(1, bo, 1);                                                                                            \
+    DK_MMG(0, 0, 0, 4, i + 2, 4, 4, PH, ON2);                                                                    \
+    DK_RDW(1, wo_cur, 1);                                                                                        \
     DK_RDA_LO(0, bo, 1);                                                                                         \
     DK_WAIT4(8, xf1);                                                                                            \
-    DK_MMG(0, 1, 4, NHI, i + 1, DK_V3_N3 + DK_V3_N0, DK_V3_N1, PH, ON1);                                         \
+    DK_MMG(0, 1, 4, NHI, i + 2, 0, 0, PH, false);                                                                \
     DK_RDA_HI(1, bo, 1);                                                                                         \
     DK_WAIT8_HI(wf1, xf0);                                                                                       \
-    DK_MMG(1, 0, 0, 4, i + 1, DK_V3_N3 + DK_V3_N0 + DK_V3_N1, DK_V3_N2, PH, ON1);                                \
-    DK_TILE_WAIT(xf1);                                                                                           \
+    DK_MMG(1, 0, 0, 4, i + 2, 0, 0, PH, false);                                                                  \
+    DK_TILE_WAIT(xf1, ON2);                                                                                      \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
-    DK_RDW(0, bo ^ KT_BYTES, 0); /* unconditional: after the last tile these read stale ring data that */        \
-    DK_RDA_LO(0, bo ^ KT_BYTES, 0); /* nobody uses; they are waited for behind the loop                  */        \
-    DK_MMG(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2);                                                           \
+    DK_RDW(0, wo_nxt, 0); /* unconditional: after the last tile these read stale ring data that */               \
+    DK_RDA_LO(0, bo ^ OP_BYTES, 0); /* nobody uses; they are waited for behind the loop          */               \
+    DK_MMG(1, 1, 4, NHI, i + 2, 0, 4, PH, ON2);                                                                  \
+    DK_ROTATE_W();                                                                                               \
   }
 // The same K-tile for the second wave of each SIMD with its fragment reads behind MFMA slot R of every step instead of
 // in front of it, so that the two waves of a SIMD do not run their read / wait sections at the same time (+1.5-2 %).
 #define DK_ITER_SKEW(PH, R, ON1, ON2)                                                                            \
   {                                                                                                              \
     constexpr bool in_loop = true;                                                                               \
-    const unsigned bo = (i & 1) * KT_BYTES;                                                                      \
+    const unsigned bo = (i & 1) * OP_BYTES;                                                                      \
     constexpr int RH = (R) * NHI / 4; /* the same relative slot inside a hi step of 4 * NHI MFMAs */            \
     DK_WAIT8(0, wf0, xf0);                                                                                       \
-    DK_MMGR(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, 0, R);                                               \
+    DK_MMGR(0, 0, 0, 4, i + 2, 4, 4, PH, ON2, 0, R);                                                             \
     DK_RDA_HI(1, bo, 0);                                                                                         \
-    DK_MMGR(0, 0, 0, 4, i + 1, DK_V3_N3, DK_V3_N0, PH, ON1, R, 16);                                              \
+    DK_MMGR(0, 0, 0, 4, i + 2, 4, 4, PH, ON2, R, 16);                                                            \
     DK_WAIT4(0, xf1);                                                                                            \
-    DK_MMGR(0, 1, 4, NHI, i + 1, 0, 0, 0, false, 0, RH);                                                         \
-    DK_RDW(1, bo, 1);                                                                                            \
+    DK_MMGR(0, 1, 4, NHI, i + 2, 0, 0, 0, false, 0, RH);                                                         \
+    DK_RDW(1, wo_cur, 1);                                                                                        \
     DK_RDA_LO(0, bo, 1);                                                                                         \
-    DK_MMGR(0, 1, 4, NHI, i + 1, 0, 0, 0, false, RH, 4 * NHI);                                                   \
+    DK_MMGR(0, 1, 4, NHI, i + 2, 0, 0, 0, false, RH, 4 * NHI);                                                   \
     DK_WAIT8(0, wf1, xf0);                                                                                       \
-    DK_MMGR(1, 0, 0, 4, i + 1, 0, 0, 0, false, 0, R);                                                            \
+    DK_MMGR(1, 0, 0, 4, i + 2, 0, 0, 0, false, 0, R);                                                            \
     DK_RDA_HI(1, bo, 1);                                                                                         \
-    DK_MMGR(1, 0, 0, 4, i + 1, 0, 0, 0, false, R, 16);                                                           \
-    DK_TILE_WAIT(xf1);                                                                                           \
+    DK_MMGR(1, 0, 0, 4, i + 2, 0, 0, 0, false, R, 16);                                                           \
+    DK_TILE_WAIT(xf1, ON2);                                                                                      \
     if (!(DK_V3_ABL & 4)) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                               \
-    DK_MMGR(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2, 0, RH);                                                   \
-    DK_RDW(0, bo ^ KT_BYTES, 0);                                                                                 \
-    DK_RDA_LO(0, bo ^ KT_BYTES, 0);                                                                              \
-    DK_MMGR(1, 1, 4, NHI, i + 2, 0, DK_V3_N3, PH, ON2, RH, 4 * NHI);                                             \
+    DK_MMGR(1, 1, 4, NHI, i + 2, 0, 4, PH, ON2, 0, RH);                                                          \
+    DK_RDW(0, wo_nxt, 0);                                                                                        \
+    DK_RDA_LO(0, bo ^ OP_BYTES, 0);                                                                              \
+    DK_MMGR(1, 1, 4, NHI, i + 2, 0, 4, PH, ON2, RH, 4 * NHI);                                                    \
+    DK_ROTATE_W();                                                                                               \
   }
 // all K-tiles of this workgroup: branch-free steady state, then the two tiles that issue less.  The fragments in flight
 // at a section boundary are waited for there (an inline-asm load must not be in flight across a compiler-visible merge).
+#define DK_ROTATE_W()           \
+  do {                          \
+    const unsigned t_ = wo_cur; \
+    wo_cur = wo_nxt;            \
+    wo_nxt = wo_nn;             \
+    wo_nn = t_;                 \
+  } while (0)
 #define DK_DRIVE(ITER, ...)                                                                                      \
   {                                                                                                              \
     int i = 0;                                                                                                   \
@@ -352,12 +359,13 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 
   {
     bf16x8 wf0[4], wf1[4], xf0[4], xf1[4];
-    // prologue: K-tile 0 completely, and the first part of K-tile 1 (the steady state issues the rest in its first step)
-    issue_tile(0);
+    // prologue: K-tile 0, then K-tile 1 (the loop's first wait lets only its own four weight pieces, of K-tile 2, stay in flight)
+#pragma unroll
+    for (int gidx = 0; gidx < 8; ++gidx) issue_piece_to(0, gidx, wo_cur);
     if (nk > 1) {
 #pragma unroll
-      for (int gidx = 0; gidx < DK_V3_N3; ++gidx) issue_piece(1, gidx);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DK_V3_N3) : "memory");
+      for (int gidx = 0; gidx < 8; ++gidx) issue_piece_to(1, gidx, wo_nxt);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -367,11 +375,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     //  live across a compiler-visible branch, see gemm256sk.hip)
     constexpr bool in_loop = false;
     if (wm == 0) {
-      DK_RDW(0, 0u, 0);
+      DK_RDW(0, wo_cur, 0);
       DK_RDA_LO(0, 0u, 0);
       DK_DRIVE(DK_ITER, DK_V3_PH0)
     } else {
-      DK_RDW(0, 0u, 0);
+      DK_RDW(0, wo_cur, 0);
       DK_RDA_LO(0, 0u, 0);
 #if DK_V3_SKEW
       DK_DRIVE(DK_ITER_SKEW, DK_V3_PH1, DK_V3_SKEW_R)
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_ITER
 #undef DK_ITER_SKEW
 #undef DK_DRIVE
+#undef DK_ROTATE_W
 
   // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
   // All waves passed the last loop barrier after their final ds_read, so the ring is free.
