@@ -16,7 +16,7 @@
 //   C   bf16 like the bf16 kernels, or MX-fp8 (same format as A) when the consumer is another fp8 GEMM.
 //
 // Kernel shape = the bf16 kernel's (gemm256v3.hip): 8 waves (2 x 4), wave tile 128 (m) x 64 (n), LDS-DMA
-// (buffer_load_dwordx4 ... lds) into a 2-deep ring of 64 KiB K-tiles, hand-counted LDS waits, LDS-staged row-major tail.
+// (buffer_load_dwordx4 ... lds) into a ring of two activation + three weight slots of 32 KiB (see LDS_BYTES), hand-counted LDS waits, LDS-staged row-major tail.
 // A K-tile is 128 fp8 = 128 bytes per row -- byte-for-byte the bf16 kernel's 64-element tile, so DMA, ring and bank
 // behaviour carry over -- and ONE MFMA per (16 x 16) fragment pair consumes it whole: 32 MFMAs of 2 x 16 x 16 x 128 flop per
 // wave and K-tile, each twice as long as a bf16 16x16x32 one, i.e. the same MFMA time per K-tile for twice the K depth.

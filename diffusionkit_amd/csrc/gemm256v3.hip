@@ -112,7 +112,11 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int base, int count) {
   return start + ((bid - base) >> 3);
 }
 
-template <int MF>
+// CONV: the activation operand is the im2col view of an NHWC tensor (3x3, pad 1, stride 1, optionally over the nearest-x2
+// upsampling of the stored tensor -- vae.py:20-25,73,79,134): GEMM row m = output pixel (b, y, x), K-tile = 64 channels of one
+// tap.  Per DMA piece the lane offset is recomputed from the pixel and the tap (a dozen VALU instructions); padding taps take
+// an offset beyond the buffer descriptor's range, for which the LDS-DMA writes zeros (scripts/oob_probe.hip).
+template <int MF, bool CONV>
 __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, SplitArgs sp) {
   static_assert(MF == 8 || MF == 7, "wave tile: 8 or 7 fragments of 16 rows");
   constexpr int BM = 32 * MF;     // tile rows (two wave rows)
@@ -174,34 +178,64 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 
   // DMA sources: A rows through the segment map per lane (32-bit byte offsets from p.A; rows beyond M - 1 re-read
   // the last row, their results are never stored), W rows from a tile-uniform base + lane part
-  unsigned la[2][2], lw[2];
+  unsigned la[2][2], lw[2];  // (CONV: la = the row's pixel, b << 24 | y << 12 | x)
+  unsigned lch[2] = {0u, 0u};  // CONV: byte offset of the lane's 16-byte chunk inside a 128-byte K-tile row
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane&7) ^ (((wave*16 + j*8 + srow) >> 1) & 7)
     lw[j] = ((unsigned)srow * (unsigned)p.ldw + chunk * 8) * 2u;
+    lch[j] = (unsigned)chunk * 16u;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       // (MF = 7: wave 7's rows lie beyond the 112 rows a wave row uses -- it fetches duplicates of other rows into LDS rows
       //  nobody reads, so that every wave issues the same 8 pieces per K-tile)
       const int m = min(m0 + hh * HROWS + wave * 16 + j * 8 + srow, p.M - 1);
-      const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
-      la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
+      if (CONV) {
+        const int hw = p.cH * p.cW;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.cW, x = rem - y * p.cW;
+        la[hh][j] = ((unsigned)b << 24) | ((unsigned)y << 12) | (unsigned)x;
+      } else {
+        const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
+        la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
+      }
     }
   }
-  const char* gA = (const char*)p.A + (size_t)k0 * (BK * 2);
+  // CONV: tap (dy, dx in -1..1) and channel byte offset of the NEXT activation K-tile to be issued; stored tensor [cB, Hs, Ws, cC]
+  const int cv_ush = CONV && p.ups == 1 ? 1 : 0;
+  const int cv_Hs = p.cH >> cv_ush, cv_Ws = p.cW >> cv_ush;
+  const int cv_C2 = p.cC * 2;
+  int cv_dy = -1, cv_dx = -1, cv_cb = 0;
+  if (CONV) {
+    const int cpt = p.cC / BK;
+    const int tap = k0 / cpt;
+    cv_cb = (k0 - tap * cpt) * (BK * 2);
+    cv_dy = tap / 3 - 1;
+    cv_dx = tap - (tap / 3) * 3 - 1;
+  }
+  const char* gA = (const char*)p.A + (CONV ? (size_t)0 : (size_t)k0 * (BK * 2));
   const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2 + (size_t)k0 * (BK * 2);
   const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
 
   // LDS-DMA in the buffer form: SGPR resource (base, 4 GiB range) + 32-bit lane offset + scalar offset -- no 64-bit
   // per-lane address and no VALU per piece
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, CONV ? p.cB * cv_Hs * cv_Ws * cv_C2 : -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
   // ring slots (byte offsets from W_BASE) of the weights of K-tiles i, i+1, i+2 of the loop below
   unsigned wo_cur = 0u, wo_nxt = OP_BYTES, wo_nn = 2u * OP_BYTES;
   // one of the 8 DMA instructions of K-tile i: gidx 0..3 the activation pieces (half, j), 4..7 the weight pieces into slot `wslot`
   auto issue_piece_to = [&](int i, int gidx, unsigned wslot) {
     const int hh = gidx & 1, j = (gidx >> 1) & 1;
-    if (gidx < 4)
+    if (gidx < 4 && CONV) {
+      const unsigned pc = la[hh][j];
+      const int iy = (int)((pc >> 12) & 0xFFFu) + cv_dy, ix = (int)(pc & 0xFFFu) + cv_dx;
+      const bool ok = (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+      const int spix = ((int)(pc >> 24) * cv_Hs + (iy >> cv_ush)) * cv_Ws + (ix >> cv_ush);
+      const unsigned voff = ok ? (unsigned)spix * (unsigned)cv_C2 + lch[j] : 0x80000000u;  // padding tap: out of range -> zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + (i & 1) * OP_BYTES + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024),
+                                               16, (int)voff, cv_cb, 0, 0);
+    } else if (gidx < 4)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)((lds_char*)0 + (i & 1) * OP_BYTES + (wave * 16) * 128 + hh * HALF_BYTES + j * 1024),
                                                16, (int)la[hh][j], ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
     else
@@ -209,6 +243,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
                                                16, (int)lw[j], (int)(hh * w128 + j * w8) + ((DK_V3_ABL & 128) ? 0 : i) * (BK * 2), 0, 0);
   };
   auto issue_piece = [&](int i, int gidx) { issue_piece_to(i, gidx, wo_nn); };  // the loop only ever issues K-tile i+2
+  auto conv_advance = [&]() {  // CONV: the activation pieces of one K-tile are out -- on to the next 64 channels / the next tap
+    if (CONV) {
+      cv_cb += BK * 2;
+      if (cv_cb == cv_C2) {
+        cv_cb = 0;
+        if (++cv_dx == 2) cv_dx = -1, ++cv_dy;
+      }
+    }
+  };
 
   f32x4 acc[4][MF];  // [nf][mf]
 #pragma unroll
@@ -342,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     wo_cur = wo_nxt;            \
     wo_nxt = wo_nn;             \
     wo_nn = t_;                 \
+    conv_advance();             \
   } while (0)
 #define DK_DRIVE(ITER, ...)                                                                                      \
   {                                                                                                              \
@@ -362,9 +406,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     // prologue: K-tile 0, then K-tile 1 (the loop's first wait lets only its own four weight pieces, of K-tile 2, stay in flight)
 #pragma unroll
     for (int gidx = 0; gidx < 8; ++gidx) issue_piece_to(0, gidx, wo_cur);
+    conv_advance();
     if (nk > 1) {
 #pragma unroll
       for (int gidx = 0; gidx < 8; ++gidx) issue_piece_to(1, gidx, wo_nxt);
+      conv_advance();
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -577,7 +623,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 }
 
 bool dk_gemm256v3_eligible(const GemmParams& p) {
-  if (p.conv || p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldc % 8 != 0) return false;
+  if (p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || (!p.conv && p.lda % 8 != 0) || p.ldw % 8 != 0 || p.ldc % 8 != 0) return false;
+  if (p.conv) {  // 3x3 / pad 1 / stride 1 (optionally over the nearest-x2 view); pixel packed as b:8 | y:12 | x:12, 31-bit byte offsets
+    if (p.ups < 0 || p.ups > 1 || p.cC % BK != 0 || p.K != 9 * p.cC || p.M != p.cB * p.cH * p.cW || p.n_split != 0) return false;
+    if (p.cB > 256 || p.cH > 4096 || p.cW > 4096 || (p.ups == 1 && (p.cH % 2 != 0 || p.cW % 2 != 0))) return false;
+    if ((size_t)p.cB * (p.cH >> p.ups) * (p.cW >> p.ups) * p.cC * 2 >= (1ull << 31) || ((uintptr_t)p.A & 15) != 0) return false;
+  }
   if (p.n_split % 256 != 0 || (p.n_split > 0 && (p.C2 == nullptr || p.ldc2 % 8 != 0 || p.n_split >= p.N))) return false;
   if (p.a_seg_len <= 0 || p.c_seg_len <= 0) return false;
   const bool res1 = p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES;
@@ -589,7 +640,7 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
   if (!al16(p.C) || !al16(p.C2) || !al16(p.res) || !al16(p.bias) || !al16(p.gate) || (p.gate != nullptr && p.gate_stride % 8 != 0)) return false;
   // 32-bit byte offsets on the DMA side: the A rows this problem touches and 8 rows of W
   const size_t a_rows = (size_t)((p.M - 1) / p.a_seg_len) * p.a_seg_stride + (size_t)((p.M - 1) % p.a_seg_len) + 1;
-  return a_rows * (size_t)p.lda * 2 < (1ull << 32) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
+  return (p.conv || a_rows * (size_t)p.lda * 2 < (1ull << 32)) && (size_t)p.ldw * 2 * 8 < (1ull << 31);
 }
 
 // dk_tune_set("gemm_split", v): -1 (default) split a remainder wave of at most half the CUs into equal pieces when the
@@ -655,8 +706,10 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int dev = 0;
     DK_CHECK_HIP(hipGetDevice(&dev));
     DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -678,10 +731,15 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
     sp.error_word = sp.flags + 512;
   }
   const int grid = pl.n_dp + pl.n_rem * pl.S;
-  if (mf == 8)
-    hipLaunchKernelGGL(dk_gemm256v3_kernel<8>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+  if (p.conv) {
+    if (mf == 8)
+      hipLaunchKernelGGL((dk_gemm256v3_kernel<8, true>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+    else
+      hipLaunchKernelGGL((dk_gemm256v3_kernel<7, true>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+  } else if (mf == 8)
+    hipLaunchKernelGGL((dk_gemm256v3_kernel<8, false>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
   else
-    hipLaunchKernelGGL(dk_gemm256v3_kernel<7>, dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
+    hipLaunchKernelGGL((dk_gemm256v3_kernel<7, false>), dim3(grid), dim3(512), LDS_BYTES, stream, p, pb, tiles_a, tiles_b, sp);
   return 0;
 }
 
@@ -689,6 +747,7 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream) {
   DK_REQUIRE(dk_gemm256v3_eligible(p), "gemm256v3: shape / strides not eligible");
   if (p2) {
+    DK_REQUIRE(!p.conv && !p2->conv, "gemm256v3: no grouped convolutions");
     DK_REQUIRE(dk_gemm256v3_eligible(*p2), "gemm256v3: second problem not eligible");
     DK_REQUIRE(p2->N == p.N && p2->K == p.K && p2->epi == p.epi && p2->alpha == p.alpha && p2->n_split == p.n_split &&
                    (p.n_split == 0 || p2->epi2 == p.epi2),
@@ -696,7 +755,7 @@ int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t s
   }
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
-  dk_prof_begin(0, work, stream);
+  dk_prof_begin(p.conv ? 1 : 0, work, stream);
   const int rc = dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, 0, p2 ? 1 : 0, stream);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());

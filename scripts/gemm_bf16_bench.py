@@ -12,6 +12,8 @@ dev = torch.device("cuda", 0)
 shapes = [("qkv img", 4096, 9216, 3072), ("o_proj img", 4096, 3072, 3072), ("fc1 img", 4096, 12288, 3072), ("fc2 img", 4096, 3072, 12288),
           ("linear1", 4352, 21504, 3072), ("linear2", 4352, 3072, 15360), ("sd3 qkv", 8192, 4608, 1536), ("sd3 fc1", 8192, 6144, 1536),
           ("sd3 fc2", 8192, 1536, 6144)]
+if os.environ.get("SWEEP"):  # per-round fixed cost: the same 768 tiles (3 rounds of 256 CUs) at growing K; 204 tiles (one round)
+    shapes = [(f"N12288 K{k}", 4096, 12288, k) for k in (512, 1024, 2048, 3072, 6144)] + [(f"N3072 K{k}", 4352, 3072, k) for k in (1024, 3072, 6144, 15360)]
 g = torch.Generator(device=dev).manual_seed(0)
 ncopy = int(os.environ.get("COLD_W", "1"))
 out = []

@@ -237,6 +237,41 @@ def test_conv3x3(dev, B, H, W, C, O, ups, res):
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
 
 
+@pytest.mark.parametrize("B,H,W,C,O,ups,res,mode", [(1, 40, 24, 64, 256, False, False, 9),    # ragged M (960 pixels), forced
+                                                    (2, 16, 24, 128, 256, False, True, 9),   # two images: no tap crosses an image border
+                                                    (1, 12, 16, 64, 512, True, False, 9),    # nearest-x2 view folded into the gather
+                                                    (1, 224, 224, 64, 256, False, True, -1),  # 196 tiles: the automatic choice
+                                                    (1, 112, 112, 64, 256, True, False, -1)])
+@pytest.mark.parametrize("mf", [8, 7])
+def test_conv3x3_on_256_tile_kernel(dev, B, H, W, C, O, ups, res, mode, mf):
+    """Convolutions with O % 256 == 0 on dk_gemm256v3_kernel<MF, CONV = true> (im2col rows recomputed per DMA piece, padding taps
+    through out-of-range buffer offsets): against the oracle and against the 128^2-tile kernel (same products, other summation order)."""
+    from diffusionkit_amd import ops
+    x = randn(B, H, W, C, seed=20)
+    w = randn(O, 3, 3, C, seed=21, scale=0.05)
+    b = randn(O, seed=22, scale=0.1)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    r = randn(B, Ho, Wo, O, seed=23) if res else None
+    args = (g(x, dev), g(w, dev), g(b, dev))
+    kw = dict(upsample=ups, res=g(r, dev) if res else None)
+    try:
+        ops.tune("gemm", mode)
+        ops.tune("gemm_mf", mf)
+        y = ops.conv3x3(*args, **kw)
+        ops.tune("gemm", 128)
+        y128 = ops.conv3x3(*args, **kw)
+    finally:
+        ops.tune("gemm", -1)
+        ops.tune("gemm_mf", -1)
+    xin = ov.upsample_nearest(x) if ups else x
+    ref = ov.conv2d_nhwc(xin, w, b, Prec())
+    if res:
+        ref = ref + r
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+    assert max_abs(y128.float(), y.float()) <= 0.02 * float(ref.abs().max()) + 1e-2
+    assert float((y128.float() != y.float()).float().mean()) < 0.05
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(1024, 768, 640, "gate_res"),     # 12 tiles: 4 equal pieces per tile
                                        (1178, 512, 384, "bias"),         # ragged M, 10 tiles
                                        (3328, 2560, 256, "gelu"),        # 130 tiles > half the CUs: finisher + 1 producer
