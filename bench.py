@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="dk_tune_set knob for A/B runs, e.g. --tune gemm_sched=0 (default kernels otherwise)")
+                    help="dk_tune_set knob for A/B runs, e.g. --tune gemm_mf=8 (default kernels otherwise)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -32,9 +32,9 @@ struct GemmParams {
   int conv;
   int cB, cH, cW, cC, ups;
   const bf16_t* zeros;  // >= 128 B of zeros (padding taps)
-  void* workspace;      // optional stream-K workspace (dk_streamk_workspace_bytes()), else null
+  void* workspace;      // optional K-split workspace (dk_gemm_split_workspace_bytes()), else null
   size_t workspace_bytes;
-  // optional column split (256^2 v2 kernel only): output columns >= n_split go to C2 (leading dim ldc2, same row
+  // optional column split (256^2 kernel only): output columns >= n_split go to C2 (leading dim ldc2, same row
   // map as C, column index rebased to 0) with epilogue epi2 -- the fused linear1 of the single-stream blocks
   // (q/k/v projection | fc1 + GELU over one read of the modulated activations, mmdit.py:693-751)
   int n_split;
@@ -43,16 +43,12 @@ struct GemmParams {
   int epi2;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
-int dk_launch_gemm256(const GemmParams& p, int variant, hipStream_t stream);  // gemm256.hip
 extern int g_dk_gemm_mode;
-extern int g_dk_v2_sched;
 extern int g_dk_v3_split;  // gemm256v3.hip: remainder-wave K split (-1 auto, 0 off, 1 whenever possible)
 extern int g_dk_v3_mf;     // gemm256v3.hip: wave-tile height in 16-row fragments (-1 auto, 8 = 256-row tiles, 7 = 224-row tiles)
-// stream-K form (persistent grid, fp32 slabs + flags in a caller-owned workspace whose last 4 KiB
-// -- the flag region -- must be zero before the first launch; kernels leave it zero)
-size_t dk_streamk_workspace_bytes();
-bool dk_gemm256v2_eligible(const GemmParams& p);
-int dk_launch_gemm256v2(const GemmParams& p, const GemmParams* p2, bool streamk, hipStream_t stream);  // gemm256sk.hip
+// workspace of the remainder-wave K split (fp32 slabs + flags; its last 4 KiB -- the flag region -- must be zero before the first
+// launch; the kernels leave it zero)
+size_t dk_gemm_split_workspace_bytes();
 bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 256 == 0, K % 64 == 0, any M, any row-segment maps
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream);  // gemm256v3.hip (16x16x32 MFMA K loop)

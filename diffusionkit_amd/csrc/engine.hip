@@ -30,7 +30,6 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
-  if (strcmp(key, "gemm_sched") == 0) { g_dk_v2_sched = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
@@ -60,7 +59,7 @@ static GemmParams gemm_params_from_desc(const dk_gemm_desc* d) {
   return p;
 }
 
-extern "C" size_t dk_gemm_workspace_bytes(void) { return dk_streamk_workspace_bytes(); }
+extern "C" size_t dk_gemm_workspace_bytes(void) { return dk_gemm_split_workspace_bytes(); }
 
 extern "C" int dk_gemm_bf16(const dk_gemm_desc* d, void* stream) {
   DK_REQUIRE(d != nullptr, "null descriptor");
@@ -275,7 +274,7 @@ static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_s
   p.r_seg_len = r_seg_len > 0 ? r_seg_len : M; p.r_seg_stride = r_seg_stride;
   p.gate_seg_len = gate_seg_len > 0 ? gate_seg_len : M; p.gate_stride = gate_stride;
   p.alpha = 1.0f; p.epi = epi;
-  if (g_linear_ws) { p.workspace = g_linear_ws; p.workspace_bytes = dk_streamk_workspace_bytes(); }
+  if (g_linear_ws) { p.workspace = g_linear_ws; p.workspace_bytes = dk_gemm_split_workspace_bytes(); }
   return p;
 }
 
@@ -334,7 +333,7 @@ struct dk_mmdit {
   bf16_t* CTXE = nullptr;  // context_embedder(text) [B, S_t, h], step-invariant (dk_mmdit_cache_context)
   bool ctx_ready = false;
   int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
-  void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_streamk_workspace_bytes()
+  void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_gemm_split_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
   // guidance embedding (cfg.guidance_embed): MLPEmbedder weights, the value set by dk_mmdit_set_guidance, scratch rows
@@ -549,7 +548,7 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->gvec = (bf16_t*)c.take(m->cfg.guidance_embed ? (size_t)h * 2 : 0);
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
-  m->GWS = c.take(dk_streamk_workspace_bytes());
+  m->GWS = c.take(dk_gemm_split_workspace_bytes());
   return c.off;
 }
 
@@ -591,7 +590,7 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
                                   (size_t)mh * m->h() * 2, (size_t)gw * m->h() * 2, gh, hipMemcpyDeviceToDevice, st));
   }
   // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
-  DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_streamk_workspace_bytes() - 4096, 0, 4096, st));
+  DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
   g_linear_ws = m->GWS;
   m->prepared = true;
   m->mod_ready = false;

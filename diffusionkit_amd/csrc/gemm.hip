@@ -230,27 +230,22 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-// tuning knob (dk_tune_set("gemm", v)): -1 = automatic choice, 128 = always the 128^2 kernel,
-// 0 / 1 = always the 256^2 kernel with that schedule variant (when the shape allows it)
+// tuning knob (dk_tune_set("gemm", v)): -1 = automatic choice, 128 = always the 128^2-tile kernel of this file, 9 = the 256^2 kernel
+// (gemm256v3.hip) on every shape it accepts
 int g_dk_gemm_mode = -1;
-
-// Kernel choice from the kernel-lab measurements (profiles/r01_gemm_lab.md): the 256^2 kernel has the
-// better per-CU rate (fewer L2->LDS bytes per FLOP) but one workgroup per CU, so it pays when its
-// tiles fill the 256 CUs well: a single wave of >= 60 % of the CUs, or several waves at >= 78 %.
-static bool prefer_256(const GemmParams& p) {
-  if (p.conv || p.N % 256 != 0 || p.M < 1024) return false;
-  const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
-  const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-  return t256 <= 256 ? eff256 >= 0.60 : eff256 >= 0.78;
-}
 
 int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
   if (p.ldw <= 0) p.ldw = p.K;
   DK_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
-  if (p.n_split > 0 && !(g_dk_gemm_mode == -1 && dk_gemm256v2_eligible(p) && p.M >= 1024)) {
-    // column-split GEMM on a kernel without split support: two GEMMs over the two column ranges
+  // the 256^2 kernel (16x16x32 MFMA, LDS-DMA ring, any M and any row-segment map) takes every large-M shape it accepts; small M
+  // (modulation tables, embedders, a lone text stream) and N % 256 != 0 stay on the 128^2 tiles
+  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9);
+  if (g_dk_gemm_mode == 9 && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
+  if (big) return dk_launch_gemm256v3(p, nullptr, stream);
+  if (p.n_split > 0) {
+    // column-split GEMM on the kernel without split support: two GEMMs over the two column ranges
     DK_REQUIRE(p.n_split < p.N && p.C2 != nullptr, "bad column split");
     GemmParams a = p, b = p;
     a.N = p.n_split; a.n_split = 0;
@@ -258,31 +253,6 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     b.C = p.C2; b.ldc = p.ldc2; b.epi = p.epi2;
     const int rc = dk_launch_gemm(a, stream);
     return rc ? rc : dk_launch_gemm(b, stream);
-  }
-  if (!p.conv && g_dk_gemm_mode != 128 && p.N % 4 == 0 && p.K % 64 == 0 && p.lda % 8 == 0) {
-    const bool v2_ok = dk_gemm256v2_eligible(p);
-    const bool sk_ok = v2_ok && p.workspace != nullptr && p.M >= 1024;
-    if (g_dk_gemm_mode == 3) {
-      DK_REQUIRE(sk_ok, "stream-K forced but the shape / workspace does not allow it");
-      return dk_launch_gemm256v2(p, nullptr, true, stream);
-    }
-    if (g_dk_gemm_mode == 9) {  // 16x16x32-MFMA kernel on anything it accepts (ragged M, segment-straddling tiles)
-      DK_REQUIRE(dk_gemm256v3_eligible(p), "gemm256v3 forced but the shape does not allow it");
-      return dk_launch_gemm256v3(p, nullptr, stream);
-    }
-    if (g_dk_gemm_mode >= 6 && g_dk_gemm_mode <= 8) {  // 6: grouped DMA issue, 7 / 8: interleaved anti-phase DMA issue (4+4 / 3+3+2)
-      DK_REQUIRE(v2_ok, "gemm256v2 forced but the shape does not allow it");
-      const int saved = g_dk_v2_sched;
-      g_dk_v2_sched = g_dk_gemm_mode - 6;
-      const int rc = dk_launch_gemm256v2(p, nullptr, false, stream);
-      g_dk_v2_sched = saved;
-      return rc;
-    }
-    if (g_dk_gemm_mode >= 0 && g_dk_gemm_mode < 128) return dk_launch_gemm256(p, g_dk_gemm_mode, stream);
-    // automatic choice (kernel lab, profiles/r01_gemm_lab_v2.log): the second-generation 256^2 kernel wins
-    // on every eligible large-M shape; ineligible shapes fall back to the first 256^2 kernel / 128^2 tiles
-    if (v2_ok && p.M >= 1024) return dk_launch_gemm256v2(p, nullptr, false, stream);
-    if (prefer_256(p)) return dk_launch_gemm256(p, 5, stream);
   }
   if (p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p)) {
     // implicit-GEMM convolutions with O % 256 == 0 ride the 256^2 kernel once their tiles fill most of the CUs (the VAE's 256^2-pixel
@@ -323,20 +293,13 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
   if (a.ldw <= 0) a.ldw = a.K;
   if (b.ldw <= 0) b.ldw = b.K;
   const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha && a.n_split == 0 && b.n_split == 0;
-  if (g_dk_gemm_mode == -1 && same && (a.M >= 1024 || b.M >= 1024)) {
-    // the third-generation kernel takes any M and any row-segment map (a ragged or segment-straddling text stream
-    // next to its image stream); the second-generation one needs both problems tile-aligned
-    const bool v3 = g_dk_v2_sched == 3 && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b);
-    const bool v2 = dk_gemm256v2_eligible(a) && dk_gemm256v2_eligible(b);
-    if (v3 || v2) {
-      // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial
-      // extra wave costs more than the small separate launch)
-      const long ta = (long)((a.M + 255) / 256) * (a.N / 256), tb = (long)((b.M + 255) / 256) * (b.N / 256);
-      // ... unless the v3 kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
-      const bool split_ok = v3 && g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
-      if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok)
-        return v3 ? dk_launch_gemm256v3(a, &b, stream) : dk_launch_gemm256v2(a, &b, false, stream);
-    }
+  if (g_dk_gemm_mode == -1 && same && (a.M >= 1024 || b.M >= 1024) && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
+    // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial extra wave costs more
+    // than the small separate launch) ...
+    const long ta = (long)((a.M + 255) / 256) * (a.N / 256), tb = (long)((b.M + 255) / 256) * (b.N / 256);
+    // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
+    const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
+    if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);
   }
   int rc = dk_launch_gemm(a, stream);
   if (rc) return rc;

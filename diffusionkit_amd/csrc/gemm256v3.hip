@@ -650,6 +650,9 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
 // spare CUs) loses on every shape but the longest-K one and is only taken when forced.
 int g_dk_v3_split = -1;
 
+// 256 fp32 tile images + 4 KiB of flags (and the error word)
+size_t dk_gemm_split_workspace_bytes() { return (size_t)256 * SLAB_FLOATS * 4 + 4096; }
+
 // How the tiles beyond the last full wave of the CUs are cut along K (see SplitArgs).  n_rem == 0: no split.
 struct SplitPlan {
   int n_dp, n_rem, S, ks;
@@ -720,7 +723,7 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   const int bm = 32 * mf;
   const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / T256);
   const int tiles_b = two ? ((pb.M + bm - 1) / bm) * (pb.N / T256) : 0;
-  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_streamk_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0;
+  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0;
   const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
   SplitArgs sp;
   memset(&sp, 0, sizeof(sp));

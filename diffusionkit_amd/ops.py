@@ -29,7 +29,7 @@ _gemm_ws = {}
 
 
 def gemm_workspace(device) -> Tensor:
-    """Zero-initialised stream-K scratch (dk_gemm_workspace_bytes), one per device."""
+    """Zero-initialised scratch of the GEMM's remainder-wave K split (dk_gemm_workspace_bytes), one per device."""
     key = str(device)
     if key not in _gemm_ws:
         _gemm_ws[key] = torch.zeros(_lib.load().dk_gemm_workspace_bytes(), dtype=torch.uint8, device=device)

@@ -66,9 +66,9 @@ typedef struct dk_gemm_desc {
   float alpha;          /* scales the accumulator before the bias (1.0 for Linear) */
   int32_t epilogue;
   int32_t ldw;          /* row stride of W in elements; 0 = K (contiguous nn.Linear weight) */
-  /* Optional scratch for the stream-K kernel (large M, N % 256 == 0): dk_gemm_workspace_bytes()
-   * bytes, 256-byte aligned, whose LAST 4096 bytes are zero before the first use (the kernels leave
-   * them zero).  NULL = tile-parallel kernels only.  One GEMM at a time may use a given workspace. */
+  /* Optional scratch for the remainder-wave K split of the 256x256 kernel (large M, N % 256 == 0):
+   * dk_gemm_workspace_bytes() bytes, 256-byte aligned, whose LAST 4096 bytes are zero before the first use (the
+   * kernels leave them zero).  NULL = no K split.  One GEMM at a time may use a given workspace. */
   void* workspace;
   size_t workspace_bytes;
 } dk_gemm_desc;
@@ -325,10 +325,11 @@ int dk_latent_sample_f32(const void* moments_bf16, int32_t ldm, const float* noi
 int dk_profile_enable(int32_t on);
 int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops, int64_t* launches);
 
-/* Tuning knobs for A/B measurements (no reference counterpart).  key "gemm": -1 automatic kernel
- * choice (default), 128 = 128x128 tiles only, 0 / 1 / 2 = 256x256 tiles (simple / staggered / spread-DMA
- * schedule), 3 = 256x256 stream-K (needs the descriptor's workspace).  key "attn": kernel variant of dk_attention_bf16 (-1 automatic).  Returns 0, or -1 for an
- * unknown key. */
+/* Tuning knobs for A/B measurements (no reference counterpart).  key "gemm": -1 automatic kernel choice (default),
+ * 128 = 128x128 tiles only, 9 = 256x256 tiles on every shape they accept; "gemm_mf": 8 / 7 = 256- / 224-row tiles;
+ * "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "attn": kernel variant of dk_attention_bf16
+ * (4 / 5 / 6 lean kernel with 4 / 8 / 7 waves, 7 / 8 pipelined kernel with 8 / 4 waves); -1 = automatic for every key.
+ * Returns 0, or -1 for an unknown key. */
 int dk_tune_set(const char* key, int32_t value);
 
 /* Row pitch, in elements, the engine expects for a weight matrix whose rows hold k elements and that it reads with a long

@@ -88,7 +88,6 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  if (getenv("LAB_SCHED")) dk_tune_set("gemm_sched", atoi(getenv("LAB_SCHED")));
   if (getenv("LAB_SPLIT")) dk_tune_set("gemm_split", atoi(getenv("LAB_SPLIT")));  // v3 remainder-wave K split: -1 auto, 0 off, 1 force
   void* ws = nullptr;
   const size_t ws_bytes = dk_gemm_workspace_bytes();

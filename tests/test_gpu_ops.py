@@ -91,18 +91,14 @@ def test_gemm_segment_mapping_in_place(dev):
     assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP
 
 
-GEMM_MODES = {128: "128^2 tiles", 0: "256^2 simple", 1: "256^2 staggered", 5: "256^2 register-pipelined",
-              6: "256^2 v2 (LDS-staged tail)", 7: "256^2 v2 interleaved DMA issue", 9: "256^2 v3 (16x16x32 MFMA)",
-              3: "256^2 v2 stream-K"}
+GEMM_MODES = {-1: "automatic choice", 128: "128^2 tiles", 9: "256^2 tiles (16x16x32 MFMA, LDS-DMA ring)"}
 
 
 @pytest.mark.parametrize("mode", sorted(GEMM_MODES))
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
 def test_gemm_kernel_variants(dev, mode, epi):
-    """Every GEMM kernel variant behind dk_tune_set("gemm", mode) against the oracle, on a shape all of
-    them accept (M, N multiples of 256; two row segments of 512), with a multi-tile K loop.  The
-    stream-K variant runs with more K-tile iterations than workgroups, so tiles are split and the
-    slab hand-off (producer / finisher) is exercised."""
+    """Both GEMM kernels behind dk_tune_set("gemm", mode) against the oracle, on a shape both accept (two row segments of 512),
+    with a multi-tile K loop (10 K-tiles: the ring of two activation and three weight slots wraps several times)."""
     from diffusionkit_amd import ops
     B, S, K, N = 2, 512, 640, 768
     M = B * S
@@ -126,13 +122,13 @@ def test_gemm_kernel_variants(dev, mode, epi):
         ops.tune("gemm", -1)
     assert rel_l2(ref, y.float()) < TOL_SINGLE_OP, GEMM_MODES[mode]
     assert max_abs(ref, y.float()) < 0.02 * float(ref.abs().max()) + 1e-2
-    # the stream-K flag region must be left zero (flags are reset by their consumer)
+    # the flag region of the K-split workspace must be left zero (flags are reset by their consumer)
     assert int(ws[-4096:].sum()) == 0
 
 
-def test_gemm_streamk_joint_stream_in_place(dev):
-    """Stream-K / v2 kernels on the image rows of a joint [B, S, h] buffer (segment maps evaluated once
-    per tile), C aliasing the residual as in post_sdpa."""
+def test_gemm_256_joint_stream_in_place(dev):
+    """The 256^2 kernel on the image rows of a joint [B, S, h] buffer (segment maps evaluated once per tile), C aliasing the
+    residual as in post_sdpa."""
     from diffusionkit_amd import ops
     B, S_t, S_i, h = 2, 256, 512, 256
     S = S_t + S_i
@@ -142,7 +138,7 @@ def test_gemm_streamk_joint_stream_in_place(dev):
     o = bf16r(att[:, S_t:] @ w.t() + b)
     ref[:, S_t:] = X[:, S_t:] + bf16r(gate[:, None, h:2 * h] * o)
     ws = ops.gemm_workspace(dev)
-    for mode in (6, 3):
+    for mode in (9, -1):
         Xd, attd, gd = g(X, dev), g(att, dev), g(gate, dev)
         try:
             ops.tune("gemm", mode)
@@ -355,12 +351,12 @@ def test_attention(dev, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 3, 1088, 128),
                                      (2, 2, 589 + 64, 64)])
 def test_attention_kernel_variants(dev, mode, B, H, S, D):
-    """Every attention kernel variant behind dk_tune_set("attn", mode) (4 / 8 waves, interleaved score
-    chains, the VALU-lean kernel with the deferred rescale) against the oracle; ragged tail tile."""
+    """Every attention kernel variant behind dk_tune_set("attn", mode) (the VALU-lean kernel with the deferred rescale at 4 / 8 / 7
+    waves, the software-pipelined kernel at 8 / 4 waves) against the oracle; ragged tail tile."""
     from diffusionkit_amd import ops
     h = H * D
     qkv = randn(B, S, 3 * h, seed=32)
@@ -387,7 +383,7 @@ def test_attention_spiked_key_forces_rescale(dev):
     p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
     ref = (p @ v[0])[None]
     assert float(p[7, 250]) > 0.9
-    for mode in (0, 4, 5, 7, 8):  # always-rescale kernel and the deferred-rescale kernels (threshold path; 7 / 8: pipelined kernel)
+    for mode in (4, 5, 7, 8):  # the deferred-rescale kernels (threshold path; 7 / 8: pipelined kernel)
         try:
             ops.tune("attn", mode)
             y = ops.attention(g(qkv, dev), H, D)
