@@ -92,6 +92,8 @@ SIGNATURES = {
     "dk_last_error": (C.c_char_p, []),
     "dk_gemm_bf16": (_i32, [C.POINTER(dk_gemm_desc), _vp]),
     "dk_gemm_workspace_bytes": (C.c_size_t, []),
+    "dk_attention_workspace_bytes": (C.c_size_t, []),
+    "dk_attention_set_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dk_conv3x3_bf16": (_i32, [C.POINTER(dk_conv_desc), _vp]),
     "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dk_attention_bias_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i32, _vp]),

@@ -14,7 +14,18 @@
 
 extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 / 5 / 6 = dk_attn2 with 4 / 8 / 7 waves; 7 / 8 = dk_attn3 with 8 / 4 waves
 
-int dk_launch_attention(const AttnParams& p, hipStream_t stream) {
+// Hand-off workspace of the balanced form of dk_attn3_fwd_kernel for the launches this host thread enqueues (an engine call sets
+// it to its own engine's region, dk_attention_set_workspace to a caller's buffer; null = plain grids only)
+static thread_local void* g_attn_ws = nullptr;
+void dk_set_attention_workspace(void* ws) { g_attn_ws = ws; }
+void* dk_get_attention_workspace() { return g_attn_ws; }
+
+int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
+  AttnParams p = p_in;
+  if (p.bal_ws == nullptr && g_attn_ws != nullptr) {
+    p.bal_ws = g_attn_ws;
+    p.bal_flags = (unsigned*)((char*)g_attn_ws + dk_attention_balance_workspace_bytes() - 4096);
+  }
   DK_REQUIRE(p.D == 128 || p.D == 64, "head_dim must be 64 or 128");
   DK_REQUIRE(p.S > 0 && p.B > 0 && p.H > 0, "empty attention");
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");

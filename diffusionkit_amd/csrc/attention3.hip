@@ -16,9 +16,21 @@
 // its end), so hipcc's scheduler can interleave the independent MFMA and VALU streams; the rare rescale of O sits behind the
 // block, after P.V(j) has completed -- the order T13 requires (decision and rescale after the pending tile's P.V, before the
 // exponentials of the tile the new maximum covers).  K runs one tile ahead of V through the same two LDS slots each.
+//
+// Balanced form (BAL): with one image the grid is 1.6 rounds of the CUs (FLUX: 408 workgroups of equal length on 256 CUs), so a
+// fifth of the chip idles through the second round whatever the workgroup size.  Here the launch has one workgroup per CU and the
+// iteration space (task = (batch, head, 256-query block)) x (64-key tiles) is cut into equal contiguous ranges, the way a stream-K
+// GEMM cuts (tile, k).  A range is at least one task long, so a task is either whole inside one range or split in two: its HEAD
+// (keys from 0) is the last segment of workgroup c, its TAIL the first segment of workgroup c+1.  The tail's owner stores its
+// unnormalised (m, l, O) to a workspace slot first thing and raises a flag (guide G16 hand-off: write-through stores, vmcnt(0) in
+// every wave, barrier, one relaxed agent-scope flag store); the head's owner still has its own (m, l, O) in registers when it
+// gets there, merges the two softmax states and writes the output.  Dependencies only point at higher workgroup indices, which
+// are dispatched later and wait for nobody's output but their own successor's: no deadlock whatever the residency.
 #include "dk_kernels.h"
 
 #define DK3_RESCALE_THR 4.0f  // natural-log units of the scaled scores
+extern int g_dk_attn_balance;
+#define DK3_SLOT_BYTES (8 * 17 * 1024)  // one partial state: 8 waves x (16 chunks of O + 1 chunk of (m, l)) x 64 lanes x 16 B
 
 template <int D, int NW>
 struct Attn3Cfg {
@@ -45,7 +57,11 @@ __device__ __forceinline__ int k3_swz(int r) { return D == 128 ? (r & 15) : ((r 
 
 typedef __attribute__((address_space(3))) char lds_char3;
 
-template <int D, int NW, bool QFUSE>
+__device__ __forceinline__ void a3_store_sc1_b128(float* ptr, f32x4 v) {  // 16-byte write-through store (no release fence needed)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+
+template <int D, int NW, bool QFUSE, bool BAL>
 __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) {
   using C = Attn3Cfg<D, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,13 +81,52 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qb = t % nq, head = (t / nq) % p.H, b = t / (nq * p.H);
+  const unsigned row_bytes = (unsigned)p.ld * 2u;
+  const int nt_task = (S + 63) / 64;  // key tiles of a task
+  // this workgroup's range of the (task, key tile) iteration space: one whole task, or (BAL) an equal share of all of them
+  int it = t * nt_task, it_end = it + nt_task;
+  if (BAL) {
+    const int total = nq * p.H * p.B * nt_task;  // (the launcher checks total * gridDim.x < 2^31)
+    it = (int)((long)t * total / (int)gridDim.x);
+    it_end = (int)((long)(t + 1) * total / (int)gridDim.x);
+  }
+  float* const my_slot = BAL ? (float*)((char*)p.bal_ws + (size_t)t * DK3_SLOT_BYTES) + (wave * 17 * 64 + lane) * 4 : nullptr;
+
+  // ---- per-thread constants: staging chunk coordinates, global lane offsets, LDS offsets (as dk_attn2_fwd_kernel) ----
+  unsigned g_off[C::NCH];   // byte offset of chunk i inside a 64-key tile (key-local row, 16-byte column)
+  unsigned ks_off[C::NCH];  // LDS store offset inside a K tile
+  unsigned vs_off[C::NCH];  // LDS store offset inside a V tile
+#pragma unroll
+  for (int i = 0; i < C::NCH; ++i) {
+    const int id = tid + C::NT * i;
+    const int kl = id / C::CPR, c8 = id % C::CPR;
+    g_off[i] = (unsigned)kl * row_bytes + (unsigned)c8 * 16u;
+    ks_off[i] = (unsigned)(kl * C::ROWB + ((c8 ^ k3_swz<D>(kl)) << 4));
+    vs_off[i] = (unsigned)((c8 >> 1) * 2048 + (kl ^ ((((c8 >> 1) & 1) << 2) | ((c8 >> 1) & 3))) * 32 + (c8 & 1) * 16);
+  }
+  // K fragment read: row l31 (+32 per sub-tile as an immediate), swizzled chunk (kk * 2 + hi) ^ swz(l31).  The chunk index of
+  // fragment kk differs from fragment 0's by an XOR with 2 kk, so ONE lane-constant register serves all fragments (one v_xor with
+  // a literal per fragment instead of D / 16 registers held across the loop)
+  const unsigned kr_base = (unsigned)(l31 * C::ROWB + ((hi ^ k3_swz<D>(l31)) << 4));
+  const int x16 = (lane >> 4) & 1, p16 = lane & 15;
+  unsigned vr_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    vr_off[par] = (unsigned)(x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8);
+
+
+  do {  // one segment: key tiles [jb, je) of task `task`
+  const int task = it / nt_task;
+  const int jb = it - task * nt_task;
+  const int je = min(nt_task, jb + (it_end - it));
+  const int nt = je - jb;
+  it += nt;
+  const int qb = task % nq, head = (task / nq) % p.H, b = task / (nq * p.H);
   const int q0 = qb * C::QB + wave * 32;
 
   const bf16_t* Qb = p.Q + (size_t)b * S * p.ld + head * D;
   const char* Kb = (const char*)(p.K + (size_t)b * S * p.ld + head * D);  // wave-uniform bases
   const char* Vb = (const char*)(p.V + (size_t)b * S * p.ld + head * D);
-  const unsigned row_bytes = (unsigned)p.ld * 2u;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][kk*16 + hi*8 .. +7]
   bf16x8 qf[D / 16];
@@ -125,28 +180,6 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
     }
   }
 
-  // ---- per-thread constants: staging chunk coordinates, global lane offsets, LDS offsets (as dk_attn2_fwd_kernel) ----
-  unsigned g_off[C::NCH];   // byte offset of chunk i inside a 64-key tile (key-local row, 16-byte column)
-  unsigned ks_off[C::NCH];  // LDS store offset inside a K tile
-  unsigned vs_off[C::NCH];  // LDS store offset inside a V tile
-#pragma unroll
-  for (int i = 0; i < C::NCH; ++i) {
-    const int id = tid + C::NT * i;
-    const int kl = id / C::CPR, c8 = id % C::CPR;
-    g_off[i] = (unsigned)kl * row_bytes + (unsigned)c8 * 16u;
-    ks_off[i] = (unsigned)(kl * C::ROWB + ((c8 ^ k3_swz<D>(kl)) << 4));
-    vs_off[i] = (unsigned)((c8 >> 1) * 2048 + (kl ^ ((((c8 >> 1) & 1) << 2) | ((c8 >> 1) & 3))) * 32 + (c8 & 1) * 16);
-  }
-  // K fragment read: row l31 (+32 per sub-tile as an immediate), swizzled chunk (kk * 2 + hi) ^ swz(l31).  The chunk index of
-  // fragment kk differs from fragment 0's by an XOR with 2 kk, so ONE lane-constant register serves all fragments (one v_xor with
-  // a literal per fragment instead of D / 16 registers held across the loop)
-  const unsigned kr_base = (unsigned)(l31 * C::ROWB + ((hi ^ k3_swz<D>(l31)) << 4));
-  const int x16 = (lane >> 4) & 1, p16 = lane & 15;
-  unsigned vr_off[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-    vr_off[par] = (unsigned)(x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8);
-
   if (C::QLDS) {
 #pragma unroll
     for (int kk = 0; kk < D / 16; ++kk)
@@ -155,7 +188,6 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   const unsigned q_lds = C::Q_OFF + wave * (32 * C::ROWB) + lane * 16;  // (same wave writes and reads: program order + lgkmcnt suffice)
 
   u32x4 kreg[C::NCH], vreg[C::NCH];
-  const int ntiles = (S + 63) / 64;
   // one operand's 64-key tile jt -> registers through a buffer descriptor: one 32-bit lane offset per chunk (shared by K and V)
   // plus a scalar tile offset -- no 64-bit per-lane addresses.  full: the tile lies inside the sequence (no row clamp)
   const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, -1, 0x00020000);
@@ -247,47 +279,48 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   f32x16 sa0, sa1, sb0, sb1;  // scores of the tile being exponentiated / of the tile after it (the roles alternate per tile)
 
   // ---- prologue: K(0), V(0), K(1) staged; S(0) and its row maximum ----
-  load_op(rK, kreg, 0, 64 <= S);
-  load_op(rV, vreg, 0, 64 <= S);
+  load_op(rK, kreg, jb, (jb + 1) * 64 <= S);
+  load_op(rV, vreg, jb, (jb + 1) * 64 <= S);
   DK3_STORE_K(0)
   DK3_STORE_V(0)
-  if (ntiles > 1) {
-    load_op(rK, kreg, 1, 128 <= S);
+  if (nt > 1) {
+    load_op(rK, kreg, jb + 1, (jb + 2) * 64 <= S);
     DK3_STORE_K(1)
   }
   __syncthreads();
   DK3_ZERO(sa0, sa1)
   DK3_QK(0, sa0, sa1)
-  if (64 > S) { DK3_MASK(0, sa0, sa1) }
+  if ((jb + 1) * 64 > S) { DK3_MASK(jb, sa0, sa1) }
   {
     float mloc;
     DK3_ROWMAX(sa0, sa1, mloc);
     DK3_RESCALE(mloc)
   }
 
-  // One tile.  CUR / NXT: score registers of tile j / j+1; slots: V(j) in j & 1, K(j+1) in (j+1) & 1; the loads fetch K(j+2) and
-  // V(j+1) and store them into K slot j & 1 and V slot (j+1) & 1 (both last read in the previous iteration).
+  // One tile (J counts from the segment's first tile jb).  CUR / NXT: score registers of tile j / j+1; slots: V(j) in j & 1,
+  // K(j+1) in (j+1) & 1; the loads fetch K(j+2) and V(j+1) and store them into K slot j & 1 and V slot (j+1) & 1 (both last read
+  // in the previous iteration).
   // HAVE_N: tile j+1 exists; LOADS: 0 none, 1 full tiles (steady state: no row clamp, no branches), 2 generic (existence and tail checks).
 #define DK3_TILE(J, PAR, C0, C1, N0, N1, HAVE_N, LOADS)                                                        \
   {                                                                                                            \
     const int j_ = (J);                                                                                        \
     bool have_k2_ = false, have_v1_ = false;                                                                   \
     if ((LOADS) == 1) {                                                                                        \
-      load_op(rK, kreg, j_ + 2, true);                                                                         \
-      load_op(rV, vreg, j_ + 1, true);                                                                         \
+      load_op(rK, kreg, jb + j_ + 2, true);                                                                    \
+      load_op(rV, vreg, jb + j_ + 1, true);                                                                    \
       have_k2_ = have_v1_ = true;                                                                              \
     } else if ((LOADS) == 2) {                                                                                 \
-      have_k2_ = j_ + 2 < ntiles;                                                                              \
-      have_v1_ = j_ + 1 < ntiles;                                                                              \
-      if (have_k2_) load_op(rK, kreg, j_ + 2, (j_ + 3) * 64 <= S);                                             \
-      if (have_v1_) load_op(rV, vreg, j_ + 1, (j_ + 2) * 64 <= S);                                             \
+      have_k2_ = j_ + 2 < nt;                                                                                  \
+      have_v1_ = j_ + 1 < nt;                                                                                  \
+      if (have_k2_) load_op(rK, kreg, jb + j_ + 2, (jb + j_ + 3) * 64 <= S);                                   \
+      if (have_v1_) load_op(rV, vreg, jb + j_ + 1, (jb + j_ + 2) * 64 <= S);                                   \
     }                                                                                                          \
     if (HAVE_N) { DK3_ZERO(N0, N1) }                                                                           \
     /* region A: exponentials of tile j || scores of tile j+1 (independent streams, one basic block) */        \
     DK3_SOFTMAX(C0, C1)                                                                                        \
     if (HAVE_N) { DK3_QK((PAR) ^ 1, N0, N1) }                                                                  \
     if ((HAVE_N) && (LOADS) != 1) {                                                                            \
-      if ((j_ + 2) * 64 > S) { DK3_MASK(j_ + 1, N0, N1) }                                                      \
+      if ((jb + j_ + 2) * 64 > S) { DK3_MASK(jb + j_ + 1, N0, N1) }                                            \
     }                                                                                                          \
     /* region B: P.V of tile j || row maximum of tile j+1 */                                                   \
     float mloc_ = -1e30f;                                                                                      \
@@ -302,16 +335,16 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   // steady state: tiles j with j + 2 full tiles behind them (K(j+2) and V(j+1) complete tiles); two tiles per trip so that the
   // score registers keep compile-time names
   int j = 0;
-  const int n_full = S / 64;  // tiles 0 .. n_full - 1 are complete
+  const int n_full = min(je, S / 64) - jb;  // the segment's tiles 0 .. n_full - 1 are complete
   for (; j + 3 < n_full; j += 2) {  // needs K(j+3), V(j+2) full for the second body: j + 3 <= n_full - 1
     DK3_TILE(j, 0, sa0, sa1, sb0, sb1, true, 1)
     DK3_TILE(j + 1, 1, sb0, sb1, sa0, sa1, true, 1)
   }
   // remaining tiles (at most 4 + the tail): generic bodies; j is even here
-  for (; j < ntiles; j += 2) {
-    if (j + 1 < ntiles) {
+  for (; j < nt; j += 2) {
+    if (j + 1 < nt) {
       DK3_TILE(j, 0, sa0, sa1, sb0, sb1, true, 2)
-      if (j + 2 < ntiles) {
+      if (j + 2 < nt) {
         DK3_TILE(j + 1, 1, sb0, sb1, sa0, sa1, true, 2)
       } else {
         DK3_TILE(j + 1, 1, sb0, sb1, sa0, sa1, false, 0)
@@ -320,6 +353,69 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
       DK3_TILE(j, 0, sa0, sa1, sb0, sb1, false, 0)
     }
   }
+
+  // ---- the segment's end: a tail hands its state over, a head merges its tail's state in, then (whole task or head) normalise
+  // and store: lane owns query q0+l31, d = dt*32 + 8g + 4hi + {0..3} ----
+  const bool seg_tail = BAL && jb > 0, seg_head = BAL && je < nt_task;
+  if (seg_tail) {
+    // (always this workgroup's first segment)  16 chunks of O, then (m, l): [chunk][lane] x 16 bytes per wave
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        a3_store_sc1_b128(my_slot + (dt * 4 + g4) * 256, f32x4{o[dt][4 * g4 + 0], o[dt][4 * g4 + 1], o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]});
+    a3_store_sc1_b128(my_slot + (D / 8) * 256, f32x4{m_run, l_run, 0.f, 0.f});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.bal_flags + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (seg_head) {
+      // (always this workgroup's last segment)  the tail belongs to workgroup t + 1, which computed it first thing
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(p.bal_flags + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 24)) {
+            __hip_atomic_store(p.bal_flags + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // error word
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const float* other = my_slot + DK3_SLOT_BYTES / 4;
+      const f32x4 ml = *(const f32x4*)(other + (D / 8) * 256);
+      const float m_new = fmaxf(m_run, ml[0]);
+      const float a_own = __builtin_amdgcn_exp2f((m_run - m_new) * c), a_oth = __builtin_amdgcn_exp2f((ml[0] - m_new) * c);
+      l_run = l_run * a_own + ml[1] * a_oth;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 ov = *(const f32x4*)(other + (dt * 4 + g4) * 256);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[dt][4 * g4 + e] = o[dt][4 * g4 + e] * a_own + ov[e] * a_oth;
+        }
+      __syncthreads();  // every wave has read the slot
+      if (tid == 0) __hip_atomic_store(p.bal_flags + t + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float lsum = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / lsum;
+    const int q = q0 + l31;
+    if (q < S) {
+      bf16_t* op = p.O + ((size_t)b * S + q) * p.ldo + head * D;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 w;
+          w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+          w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+          *(uint2*)(op + dt * 32 + 8 * g4 + 4 * hi) = w;
+        }
+    }
+  }
+  } while (BAL && it < it_end);
 #undef DK3_TILE
 #undef DK3_STORE_K
 #undef DK3_STORE_V
@@ -330,36 +426,46 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
 #undef DK3_SOFTMAX
 #undef DK3_PV
 #undef DK3_ZERO
-
-  // ---- normalise and store: lane owns query q0+l31, d = dt*32 + 8g + 4hi + {0..3} ----
-  const float lsum = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / lsum;
-  const int q = q0 + l31;
-  if (q < S) {
-    bf16_t* op = p.O + ((size_t)b * S + q) * p.ldo + head * D;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        uint2 w;
-        w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
-        w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
-        *(uint2*)(op + dt * 32 + 8 * g4 + 4 * hi) = w;
-      }
-  }
 }
 
 template <int D, int NW, bool QFUSE>
 static int launch_attn3(const AttnParams& p, hipStream_t stream) {
   using C = Attn3Cfg<D, NW>;
   static bool attr_set = false;
+  static int n_cu = 0;
   if (!attr_set) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn3_fwd_kernel<D, NW, QFUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn3_fwd_kernel<D, NW, QFUSE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn3_fwd_kernel<D, NW, QFUSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    int dev = 0;
+    DK_CHECK_HIP(hipGetDevice(&dev));
+    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
-  hipLaunchKernelGGL((dk_attn3_fwd_kernel<D, NW, QFUSE>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);
+  const long tasks = (long)nq * p.H * p.B, nt = (p.S + 63) / 64;
+  // balanced form: one workgroup per CU over equal ranges of (task, key tile); every range holds at least a whole task (so that a
+  // task is split in two at most) and the caller provided the hand-off workspace.  OPT-IN (dk_tune_set("attn_balance", 1)): FLUX,
+  // one image = 408 tasks on 256 CUs = 1.59 rounds, so the model promises +20 %; measured +7 % in isolation (270 -> 252 us:
+  // with every CU busy to the end a key tile takes 2.3 us instead of 2.0 -- the chip's clock follows its power budget, as for
+  // the GEMM's tile heights and remainder split) and nothing inside the model (848 -> 864 TF, step time unchanged;
+  // profiles/r02_attention_balanced.log), where the fused QK-norm + RoPE of the query load is paid per segment.
+  const bool bal = g_dk_attn_balance > 0 && D == 128 && NW == 8 && p.bal_ws != nullptr && p.bal_flags != nullptr && n_cu <= 1022 && tasks > n_cu &&
+                   tasks * nt * n_cu < (1l << 31);
+  if (bal)
+    hipLaunchKernelGGL((dk_attn3_fwd_kernel<D, NW, QFUSE, true>), dim3(n_cu), dim3(C::NT), C::LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((dk_attn3_fwd_kernel<D, NW, QFUSE, false>), dim3((unsigned)tasks), dim3(C::NT), C::LDS_BYTES, stream, p);
   return 0;
+}
+
+// dk_tune_set("attn_balance", v): 1 = balanced form whenever possible; -1 (default) / 0 = plain grid (see launch_attn3)
+int g_dk_attn_balance = -1;
+
+// workspace of the balanced form: one slot per CU + 4 KiB of flags (zero before the first launch; the kernels leave them zero)
+size_t dk_attention_balance_workspace_bytes() {
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+  return (size_t)(n_cu + 1) * DK3_SLOT_BYTES + 4096;
 }
 
 // waves: 8 or 4 per workgroup; no score bias (the text encoders keep dk_attn2_fwd_kernel)

@@ -129,7 +129,15 @@ struct AttnParams {
   int qn_split = 0;
   float qn_eps = 1e-6f;
   const float* q_rope = nullptr;
+  // optional hand-off workspace of the balanced form of dk_attn3_fwd_kernel (attention3.hip): dk_attention_balance_workspace_bytes()
+  // bytes = one slot per CU, then 4 KiB of flags that are zero before the first launch (the kernels leave them zero)
+  void* bal_ws = nullptr;
+  unsigned* bal_flags = nullptr;
 };
+size_t dk_attention_balance_workspace_bytes();
+void dk_set_attention_workspace(void* ws);  // attention.hip: thread-local, picked up by dk_launch_attention
+void* dk_get_attention_workspace();
+extern int g_dk_attn_balance;
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream);  // attention3.hip (two tiles in flight per wave; no score bias)

@@ -30,6 +30,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
+  if (strcmp(key, "attn_balance") == 0) { g_dk_attn_balance = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
@@ -81,6 +82,14 @@ extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) {
   DK_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "upsample: 0 plain, 1 nearest-x2 input view, 2 stride-2 (downsample)");
   if (d->upsample == 1) DK_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "upsampled conv needs even output size");
   return dk_launch_gemm(p, S_(stream));
+}
+
+extern "C" size_t dk_attention_workspace_bytes(void) { return dk_attention_balance_workspace_bytes(); }
+extern "C" int dk_attention_set_workspace(void* workspace, size_t bytes) {
+  DK_REQUIRE(workspace == nullptr || (bytes >= dk_attention_balance_workspace_bytes() && ((uintptr_t)workspace & 255) == 0),
+             "attention workspace: dk_attention_workspace_bytes() bytes, 256-byte aligned (or NULL)");
+  dk_set_attention_workspace(workspace);
+  return 0;
 }
 
 extern "C" int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t S,
@@ -251,8 +260,8 @@ struct Carver {
   }
 };
 
-// the lean attention kernel (modes -1, 4, 5, 6) can normalise / rotate the queries in its Q load; the first-generation one cannot
-static int fuse_q() { return g_dk_fuse_q && (g_dk_attn_mode < 0 || g_dk_attn_mode >= 4) ? 1 : 0; }  // (modes 7 / 8: attention3 has the fused Q load too)
+// every attention kernel can normalise / rotate the queries in its Q load
+static int fuse_q() { return g_dk_fuse_q ? 1 : 0; }
 
 // Split workspace (fp32 slabs + flags) handed to the GEMMs an engine call builds: every dk_mmdit_* entry point sets it to ITS
 // engine's region (carved from that engine's workspace) before it enqueues anything and all launches of the call are
@@ -334,6 +343,7 @@ struct dk_mmdit {
   bool ctx_ready = false;
   int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_gemm_split_workspace_bytes()
+  void* AWS = nullptr;  // hand-off workspace of the balanced attention launch (slots + flags), dk_attention_balance_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
   // guidance embedding (cfg.guidance_embed): MLPEmbedder weights, the value set by dk_mmdit_set_guidance, scratch rows
@@ -549,6 +559,7 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
   m->GWS = c.take(dk_gemm_split_workspace_bytes());
+  m->AWS = c.take(dk_attention_balance_workspace_bytes());
   return c.off;
 }
 
@@ -591,6 +602,7 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   }
   // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
   DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
+  DK_CHECK_HIP(hipMemsetAsync((char*)m->AWS + dk_attention_balance_workspace_bytes() - 4096, 0, 4096, st));
   g_linear_ws = m->GWS;
   m->prepared = true;
   m->mod_ready = false;
@@ -820,6 +832,11 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
   hipStream_t st = S_(stream);
   g_linear_ws = m->GWS;
+  struct AttnWsScope {  // this call's attention launches hand off through this engine's region; the caller's setting comes back
+    void* prev = dk_get_attention_workspace();
+    ~AttnWsScope() { dk_set_attention_workspace(prev); }
+  } attn_ws_scope;
+  dk_set_attention_workspace(m->AWS);
   const dk_mmdit_config& c = m->cfg;
   const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F(), r = c.mlp_ratio;
   const int R = m->mod_rows();

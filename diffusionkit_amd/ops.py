@@ -108,8 +108,20 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False
     return y[..., :O]
 
 
-def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None) -> Tensor:
-    """SDPA over a token-major [B, S, 3*H*D] projection buffer -> [B, S, H*D]."""
+_attn_ws = {}
+
+
+def attention_workspace(device) -> Tensor:
+    """Zero-initialised hand-off workspace of the balanced attention launch (dk_attention_workspace_bytes), one per device."""
+    key = str(device)
+    if key not in _attn_ws:
+        _attn_ws[key] = torch.zeros(_lib.load().dk_attention_workspace_bytes(), dtype=torch.uint8, device=device)
+    return _attn_ws[key]
+
+
+def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None, workspace: Optional[Tensor] = None) -> Tensor:
+    """SDPA over a token-major [B, S, 3*H*D] projection buffer -> [B, S, H*D].  ``workspace`` (attention_workspace): lets the
+    kernel run its balanced form (dk_attention_set_workspace for the duration of the call)."""
     lib = _lib.load()
     _require_cuda(qkv, "qkv", BF)
     B, S, ld = qkv.shape
@@ -117,8 +129,14 @@ def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None) -> Ten
     out = torch.empty(B, S, h, dtype=BF, device=qkv.device)
     scale = scale if scale is not None else 1.0 / math.sqrt(D)
     base = qkv.data_ptr()
-    _lib.check(lib.dk_attention_bf16(base, base + 2 * h, base + 4 * h, out.data_ptr(), B, H, S, D, ld, h, scale, _stream()),
-               "dk_attention_bf16")
+    if workspace is not None:
+        _lib.check(lib.dk_attention_set_workspace(workspace.data_ptr(), workspace.numel()), "dk_attention_set_workspace")
+    try:
+        _lib.check(lib.dk_attention_bf16(base, base + 2 * h, base + 4 * h, out.data_ptr(), B, H, S, D, ld, h, scale, _stream()),
+                   "dk_attention_bf16")
+    finally:
+        if workspace is not None:
+            lib.dk_attention_set_workspace(None, 0)
     return out
 
 

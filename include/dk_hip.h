@@ -102,6 +102,15 @@ int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream);
 int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
                       int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, void* stream);
 
+/* Optional hand-off workspace for dk_attention_bf16 launches of THIS host thread: with it and dk_tune_set("attn_balance", 1),
+ * long-sequence D = 128 launches run in a balanced form (one workgroup per CU over equal shares of the (query block, key tile)
+ * space; a split block's two halves meet through a workspace slot) -- opt-in: it gains 4-7 % on an isolated launch whose
+ * workgroups fill 1.6 rounds of the CUs and nothing inside the model.  dk_attention_workspace_bytes()
+ * bytes, 256-byte aligned, whose LAST 4096 bytes are zero before the first use (the kernels leave them zero); NULL switches the
+ * balanced form off.  One launch at a time may use a given workspace.  The engines carry their own (dk_mmdit_workspace_bytes). */
+size_t dk_attention_workspace_bytes(void);
+int dk_attention_set_workspace(void* workspace, size_t bytes);
+
 /* The same with an additive score bias (text encoders): CLIP's causal mask
  * (clip.py:83-89, one [S, ldb] table for every head: bias_head_stride 0) and T5's relative-position
  * bias (t5.py:61-88, [H, S, ldb]); scores = scale * q.k + bias.  ldb: multiple of 64, >= S. */

@@ -11,7 +11,8 @@ from diffusionkit_amd import ops
 dev = torch.device("cuda", 0)
 shapes = [("flux B1 S4352 D128", 1, 24, 4352, 128), ("flux-dev B1 S4608 D128", 1, 24, 4608, 128), ("sd3 B2 S4685 D64", 2, 24, 4096 + 589, 64),
           ("flux B4", 4, 24, 4352, 128)]
-modes = [int(m) for m in (sys.argv[1:] or ["5", "7", "4", "8"])]
+modes = sys.argv[1:] or ["5", "7", "7b", "4", "8"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
+ws = ops.attention_workspace(dev)
 if os.environ.get("ATTN_SHAPES"):
     shapes = shapes[:int(os.environ["ATTN_SHAPES"])]
 for name, B, H, S, D in shapes:
@@ -21,17 +22,19 @@ for name, B, H, S, D in shapes:
     outs = {}
     for rnd in range(5):
         for m in modes:
-            ops.tune("attn", m)
+            ops.tune("attn", int(m.rstrip("b")))
+            ops.tune("attn_balance", 1 if m.endswith("b") else 0)
             for _ in range(2):
-                y = ops.attention(qkv, H, D)
+                y = ops.attention(qkv, H, D, workspace=ws)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                y = ops.attention(qkv, H, D)
+                y = ops.attention(qkv, H, D, workspace=ws)
             e1.record()
             torch.cuda.synchronize()
             best[m] = min(best[m], e0.elapsed_time(e1) / 10)
             outs[m] = y
     ops.tune("attn", -1)
+    ops.tune("attn_balance", -1)
     ref = outs[modes[0]].float()
     print(name, "  ".join(f"m{m}: {best[m] * 1e3:7.1f} us {flops / best[m] / 1e9:7.1f} TF (max|d| vs m{modes[0]} {float((outs[m].float() - ref).abs().max()):.3g})" for m in modes), flush=True)

@@ -371,6 +371,41 @@ def test_attention_kernel_variants(dev, mode, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
+@pytest.mark.parametrize("B,H,S,qfuse", [(1, 24, 4352, False),   # FLUX: 408 tasks of 68 tiles on 256 CUs, every workgroup but the last splits a task
+                                         (1, 24, 4352 - 37, False),  # ragged tail tile inside a tail segment
+                                         (2, 17, 3000, False),     # 408 tasks again, two images
+                                         (1, 40, 2048, False)])    # 320 tasks of 32 tiles
+def test_attention_balanced_form(dev, B, H, S, qfuse):
+    """dk_attn3_fwd_kernel<.., BAL = true>: one workgroup per CU over equal ranges of (query block, key tile); a split block's
+    head merges its tail's (m, l, O) from the workspace.  Against the plain grid of the same kernel (same tiles, same order
+    inside a segment; the merge adds one rescale) and against the oracle on a slice; the flags must be left zero."""
+    from diffusionkit_amd import ops
+    D = 128
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=33)
+    ws = ops.attention_workspace(dev)
+    qd = g(qkv, dev)
+    try:
+        ops.tune("attn", 7)
+        ops.tune("attn_balance", 1)
+        y = ops.attention(qd, H, D, workspace=ws)
+        y2 = ops.attention(qd, H, D, workspace=ws)  # the slots and flags are reusable
+        ops.tune("attn_balance", 0)
+        y0 = ops.attention(qd, H, D, workspace=ws)
+    finally:
+        ops.tune("attn", -1)
+        ops.tune("attn_balance", -1)
+    assert int(ws[-4096:].sum()) == 0
+    assert torch.equal(y, y2)
+    assert max_abs(y0.float(), y.float()) < 0.02
+    assert rel_l2(y0.float(), y.float()) < 2e-3
+    hs = [0, H // 2, H - 1]  # oracle on three heads
+    q, k, v = (torch.stack([qkv[..., i * h + hh * D:i * h + (hh + 1) * D] for hh in hs], 1) for i in range(3))
+    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec())
+    got = torch.stack([y.float().cpu()[..., hh * D:(hh + 1) * D] for hh in hs], 1)
+    assert rel_l2(ref, got) < 6e-3
+
+
 def test_attention_spiked_key_forces_rescale(dev):
     """A key that dominates late in the sequence forces the online-softmax rescale path
     (guide rule 26); fp64 reference."""
