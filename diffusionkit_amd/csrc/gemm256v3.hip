@@ -502,25 +502,52 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     unpack2bf(v.w, f[6], f[7]);
   };
 
+  // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
+  auto tail_pass = [&](auto ni_c) {
+    constexpr int ni = decltype(ni_c)::value;
+    // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half.  A whole tile (no K split)
+    // stages round_bf16(alpha * acc + bias) -- what every epilogue starts from -- as bf16: half the LDS bytes of the fp32 image
+    // (64-byte rows, 16-byte chunk c at position c ^ ((row >> 2) & 3): conflict-free for these 8-byte writes and the 16-byte
+    // read-back); split tiles stage the fp32 partial sums (128-byte rows)
+    const bool bf_stage = piece < 0;
+    if (bf_stage) {
 #pragma unroll
-  for (int ni = 0; ni < (((DK_V3_ABL & 64) && p.alpha != -1234.5f) ? 0 : 2); ++ni) {  // (lab: 64 = no tail at run time)
-    // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
+      for (int nf = 0; nf < 2; ++nf) {
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          const uint2 bb = *(const uint2*)(p.bias + n0 + wn * 64 + ni * 32 + nf * 16 + 4 * q);
+          unpack2bf(bb.x, b4[0], b4[1]);
+          unpack2bf(bb.y, b4[2], b4[3]);
+        }
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int row = mf * 16 + l15;
-        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
+        for (int mf = 0; mf < MF; ++mf) {
+          const int row = mf * 16 + l15;
+          const f32x4 a = acc[ni * 2 + nf][mf];
+          uint2 w;
+          w.x = pack2bf(a[0] * p.alpha + b4[0], a[1] * p.alpha + b4[1]);
+          w.y = pack2bf(a[2] * p.alpha + b4[2], a[3] * p.alpha + b4[3]);
+          *(__attribute__((address_space(3))) u32x2*)((lds_char*)0 + reg0 + row * 64 + (((nf * 2 + (q >> 1)) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8) = u32x2{w.x, w.y};
+        }
       }
+    } else {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int row = mf * 16 + l15;
+          *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
+        }
+    }
     // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
     const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual)
     const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias && piece < 1) unpack8(*(const uint4*)(p.bias + col), bias8);
+    if (p.bias && piece == 0) unpack8(*(const uint4*)(p.bias + col), bias8);  // (whole tiles: the bias went in before staging)
     // the row loop is instantiated twice -- tile-uniform maps (FAST) or a per-lane walk through the maps -- so that
     // the common case keeps its short body (one v_add per address, batched loads)
-    auto rows = [&](auto fast_c) {
+    auto rows = [&](auto fast_c, auto bf_c) {
       constexpr bool FAST = decltype(fast_c)::value;
+      constexpr bool BF = decltype(bf_c)::value;  // bf16 image of a whole tile / fp32 image of a split tile
       if (FAST && epi == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
       // row walk of the slow path: (segment, row inside it) of this lane's current row in each map; 16 rows per step
       int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
@@ -546,10 +573,17 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
           if (epi == DK_EPI_GATE_RES)
             for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
-        const unsigned sw = (unsigned)((row >> 1) & 7);
-        f32x4 a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
-        f32x4 a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
-        if (piece >= 0) {  // split tile
+        float vv[8];
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (BF) {
+          const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
+          unpack8(make_uint4(sv[0], sv[1], sv[2], sv[3]), vv);
+        } else {
+          const unsigned sw = (unsigned)((row >> 1) & 7);
+          a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
+          a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
+        }
+        if (!BF) {  // split tile
           const size_t slab_idx = (size_t)(wm * HROWS + row) * 256 + wn * 64 + ni * 32 + rc2 * 4;
           if (piece >= 1) {
             if (!(DK_V3_ABL & 8)) {  // (lab: 8 = producers do not store)
@@ -565,11 +599,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
             for (int e = 0; e < 4; ++e) a0[e] += o0[e], a1[e] += o1[e];
           }
         }
-        float vv[8];
+        if (!BF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vv[e] = round_bf16(a0[e] * p.alpha + bias8[e]);
-          vv[4 + e] = round_bf16(a1[e] * p.alpha + bias8[4 + e]);
+          for (int e = 0; e < 4; ++e) {
+            vv[e] = round_bf16(a0[e] * p.alpha + bias8[e]);
+            vv[4 + e] = round_bf16(a1[e] * p.alpha + bias8[4 + e]);
+          }
         }
         if (epi == DK_EPI_BIAS_GELU) {
 #pragma unroll
@@ -606,10 +641,21 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         }
       }
     };
-    if (fast)
-      rows(std::true_type{});
-    else
-      rows(std::false_type{});
+    if (bf_stage) {
+      if (fast)
+        rows(std::true_type{}, std::true_type{});
+      else
+        rows(std::false_type{}, std::true_type{});
+    } else {
+      if (fast)
+        rows(std::true_type{}, std::false_type{});
+      else
+        rows(std::false_type{}, std::false_type{});
+    }
+  };
+  if (!((DK_V3_ABL & 64) && p.alpha != -1234.5f)) {  // (lab: 64 = no tail at run time)
+    tail_pass(std::integral_constant<int, 0>{});
+    tail_pass(std::integral_constant<int, 1>{});
   }
   if (piece >= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
