@@ -502,6 +502,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     unpack2bf(v.w, f[6], f[7]);
   };
 
+  // whole tiles: the bias of this lane's 16 columns (4 per 16-column fragment), all loads up front -- one latency, not one per pass
+  u32x2 bias_q[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
+  if (piece < 0 && p.bias) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bias_q[nf] = *(const u32x2*)(p.bias + n0 + wn * 64 + nf * 16 + 4 * q);
+  }
   // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
   auto tail_pass = [&](auto ni_c) {
     constexpr int ni = decltype(ni_c)::value;
@@ -513,12 +519,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     if (bf_stage) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-          const uint2 bb = *(const uint2*)(p.bias + n0 + wn * 64 + ni * 32 + nf * 16 + 4 * q);
-          unpack2bf(bb.x, b4[0], b4[1]);
-          unpack2bf(bb.y, b4[2], b4[3]);
-        }
+        float b4[4];
+        unpack2bf(bias_q[ni * 2 + nf][0], b4[0], b4[1]);
+        unpack2bf(bias_q[ni * 2 + nf][1], b4[2], b4[3]);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
           const int row = mf * 16 + l15;
@@ -545,17 +548,21 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     if (p.bias && piece == 0) unpack8(*(const uint4*)(p.bias + col), bias8);  // (whole tiles: the bias went in before staging)
     // the row loop is instantiated twice -- tile-uniform maps (FAST) or a per-lane walk through the maps -- so that
     // the common case keeps its short body (one v_add per address, batched loads)
-    auto rows = [&](auto fast_c, auto bf_c) {
+    auto rows = [&](auto fast_c, auto bf_c, auto ek_c) {
       constexpr bool FAST = decltype(fast_c)::value;
       constexpr bool BF = decltype(bf_c)::value;  // bf16 image of a whole tile / fp32 image of a split tile
-      if (FAST && epi == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
+      constexpr int EK = decltype(ek_c)::value;   // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
+      constexpr bool PLAIN = BF && EK == DK_EPI_BIAS;  // a bias-only epilogue on a bf16 image: the staged values ARE the output
+      const int ep = EK >= 0 ? EK : epi;
+      const bool hres = EK >= 0 ? (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES) : has_res;
+      if (FAST && ep == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
       // row walk of the slow path: (segment, row inside it) of this lane's current row in each map; 16 rows per step
       int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
       if (!FAST) {
         const int ms = mrow0 + rrow;
         c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
-        if (has_res) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
-        if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
+        if (hres) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
+        if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
 #pragma unroll 4
       for (int itr = 0; itr < MF; ++itr) {
@@ -566,17 +573,21 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
           valid = mrow0 + row < p.M;
           crow = (size_t)c_seg * p.c_seg_stride + c_rem;
           rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
-          if (epi == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
+          if (ep == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
           for (c_rem += 16; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
-          if (has_res)
+          if (hres)
             for (r_rem += 16; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
-          if (epi == DK_EPI_GATE_RES)
+          if (ep == DK_EPI_GATE_RES)
             for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
         float vv[8];
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
         if (BF) {
           const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
+          if (PLAIN) {
+            if (((DK_V3_ABL & 32) ? p.alpha == -1234.5f : true) && (FAST || valid)) *(u32x4*)(Cb + crow * (size_t)ldcb + ocol) = sv;
+            continue;
+          }
           unpack8(make_uint4(sv[0], sv[1], sv[2], sv[3]), vv);
         } else {
           const unsigned sw = (unsigned)((row >> 1) & 7);
@@ -606,18 +617,18 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
             vv[4 + e] = round_bf16(a1[e] * p.alpha + bias8[4 + e]);
           }
         }
-        if (epi == DK_EPI_BIAS_GELU) {
+        if (ep == DK_EPI_BIAS_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = gelu_erf_f(vv[e]);
-        } else if (epi == DK_EPI_BIAS_SILU) {
+        } else if (ep == DK_EPI_BIAS_SILU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
-        } else if (has_res) {
+        } else if (hres) {
           uint4 rr = make_uint4(0u, 0u, 0u, 0u);
           if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
           float r8[8];
           unpack8(rr, r8);
-          if (epi == DK_EPI_GATE_RES) {
+          if (ep == DK_EPI_GATE_RES) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) vv[e] = r8[e] + round_bf16(gate8[e] * vv[e]);
           } else {
@@ -641,16 +652,24 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         }
       }
     };
-    if (bf_stage) {
-      if (fast)
-        rows(std::true_type{}, std::true_type{});
+    using EkRun = std::integral_constant<int, -1>;
+    if (bf_stage && fast) {
+      // the common epilogues with the epilogue folded at compile time (no scalar branches inside the row loop)
+      if (epi == DK_EPI_BIAS)
+        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_BIAS>{});
+      else if (epi == DK_EPI_BIAS_GELU)
+        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{});
+      else if (epi == DK_EPI_GATE_RES)
+        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_GATE_RES>{});
       else
-        rows(std::false_type{}, std::true_type{});
+        rows(std::true_type{}, std::true_type{}, EkRun{});
+    } else if (bf_stage) {
+      rows(std::false_type{}, std::true_type{}, EkRun{});
     } else {
       if (fast)
-        rows(std::true_type{}, std::false_type{});
+        rows(std::true_type{}, std::false_type{}, EkRun{});
       else
-        rows(std::false_type{}, std::false_type{});
+        rows(std::false_type{}, std::false_type{}, EkRun{});
     }
   };
   if (!((DK_V3_ABL & 64) && p.alpha != -1234.5f)) {  // (lab: 64 = no tail at run time)
