@@ -352,34 +352,51 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     unpack2bf(v.w, f[6], f[7]);
   };
 
+  // the weight scales and the bias of this lane's 16 columns (4 per 16-column fragment), all loads up front
+  f32x4 ws_q[4];
+  u32x2 bias_q[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half
+  for (int nf = 0; nf < 4; ++nf) {
+    ws_q[nf] = *(const f32x4*)(p.wscale + n0 + wn * 64 + nf * 16 + 4 * q);
+    if (p.bias) bias_q[nf] = *(const u32x2*)(p.bias + n0 + wn * 64 + nf * 16 + 4 * q);
+  }
+  // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
+  auto tail_pass = [&](auto ni_c) {
+    constexpr int ni = decltype(ni_c)::value;
+    // stage round_bf16(wscale * acc + bias) -- what every epilogue starts from -- as bf16: lane owns row mf*16 + l15, columns
+    // (nf & 1)*16 + 4*q + {0..3} of this 32-column half; 64-byte rows, 16-byte chunk c at position c ^ ((row >> 2) & 3)
+    // (conflict-free for these 8-byte writes and the 16-byte read-back)
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
+    for (int nf = 0; nf < 2; ++nf) {
+      float b4[4];
+      unpack2bf(bias_q[ni * 2 + nf][0], b4[0], b4[1]);
+      unpack2bf(bias_q[ni * 2 + nf][1], b4[2], b4[3]);
+      const f32x4 w4 = ws_q[ni * 2 + nf];
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) {
         const int row = mf * 16 + l15;
-        *(__attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((nf * 4 + q) ^ ((row >> 1) & 7)) << 4)) = acc[ni * 2 + nf][mf];
+        const f32x4 a = acc[ni * 2 + nf][mf];
+        const unsigned lo = pack2bf(a[0] * w4[0] + b4[0], a[1] * w4[1] + b4[1]), hi = pack2bf(a[2] * w4[2] + b4[2], a[3] * w4[3] + b4[3]);
+        *(__attribute__((address_space(3))) u32x2*)((lds_char*)0 + reg0 + row * 64 + (((nf * 2 + (q >> 1)) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8) = u32x2{lo, hi};
       }
-    const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual, wscale)
-    const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ws8[8];
-    if (p.bias) unpack8(*(const uint4*)(p.bias + col), bias8);
-    {
-      const f32x4 w0 = *(const f32x4*)(p.wscale + col), w1 = *(const f32x4*)(p.wscale + col + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ws8[e] = w0[e], ws8[4 + e] = w1[e];
     }
-    auto rows = [&](auto fast_c) {
+    const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (gate, residual)
+    const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
+    float gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto rows = [&](auto fast_c, auto ek_c, auto mx_c) {
       constexpr bool FAST = decltype(fast_c)::value;
-      if (FAST && epi == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
+      constexpr int EK = decltype(ek_c)::value;  // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
+      constexpr int MX = decltype(mx_c)::value;  // output: 1 MX-fp8, 0 bf16, -1: `out_mx8`
+      const int ep = EK >= 0 ? EK : epi;
+      const bool hres = EK >= 0 ? (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES) : has_res;
+      const bool omx = MX >= 0 ? MX == 1 : out_mx8;
+      if (FAST && ep == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
       int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
       if (!FAST) {
         const int ms = mrow0 + rrow;
         c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
-        if (has_res) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
-        if (epi == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
+        if (hres) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
+        if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
       // MX-fp8 output on a tile-uniform row map: a lane's eight rows (itr) are the eight 16-row fragments of its 128-row block, and
       // their scale bytes are the eight consecutive bytes of ONE word of the side array (dk_mx_scale_index: byte (r / 16) % 8) --
@@ -394,34 +411,32 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           valid = mrow0 + row < p.M;
           crow = (size_t)c_seg * p.c_seg_stride + c_rem;
           rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
-          if (epi == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
+          if (ep == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
           for (c_rem += 16; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
-          if (has_res)
+          if (hres)
             for (r_rem += 16; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
-          if (epi == DK_EPI_GATE_RES)
+          if (ep == DK_EPI_GATE_RES)
             for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
-        const unsigned sw = (unsigned)((row >> 1) & 7);
-        const f32x4 a0 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)rc2 ^ sw) << 4));
-        const f32x4 a1 = *(const __attribute__((address_space(3))) f32x4*)((lds_char*)0 + reg0 + row * 128 + (((unsigned)(rc2 + 1) ^ sw) << 4));
-        float vv[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vv[e] = round_bf16(a0[e] * ws8[e] + bias8[e]);
-          vv[4 + e] = round_bf16(a1[e] * ws8[4 + e] + bias8[4 + e]);
+        const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
+        if (EK == DK_EPI_BIAS && MX == 0) {  // bias only, bf16 out: the staged values ARE the output
+          if (FAST || valid) *(u32x4*)((bf16_t*)Cb + crow * (size_t)ldcb + ocol) = sv;
+          continue;
         }
-        if (epi == DK_EPI_BIAS_GELU) {
+        float vv[8];
+        unpack8(make_uint4(sv[0], sv[1], sv[2], sv[3]), vv);
+        if (ep == DK_EPI_BIAS_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = gelu_erf_f(vv[e]);
-        } else if (epi == DK_EPI_BIAS_SILU) {
+        } else if (ep == DK_EPI_BIAS_SILU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
-        } else if (has_res) {
+        } else if (hres) {
           uint4 rr = make_uint4(0u, 0u, 0u, 0u);
           if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
           float r8[8];
           unpack8(rr, r8);
-          if (epi == DK_EPI_GATE_RES) {
+          if (ep == DK_EPI_GATE_RES) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) vv[e] = r8[e] + round_bf16(gate8[e] * vv[e]);
           } else {
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
             for (int e = 0; e < 8; ++e) vv[e] += r8[e];
           }
         }
-        if (out_mx8) {
+        if (omx) {
           // MX-fp8 output: the four lanes of a row hold one 32-column block; values are rounded to bf16 first (what the bf16
           // path would have stored), then quantised -- 8 bytes per lane, one scale byte per block
 #pragma unroll
@@ -452,18 +467,30 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           if (FAST || valid) *(uint4*)((bf16_t*)Cb + crow * (size_t)ldcb + ocol) = o4;
         }
       }
-      if (FAST && out_mx8 && (lane & 3) == 0) {
+      if (FAST && omx && (lane & 3) == 0) {
         // rows physC0 + c_row0 + rrow + 16 * {0..7}: one aligned 128-row block (the launcher checks the alignment), bytes 0..7
         const unsigned r0 = (unsigned)physC0 + (unsigned)p.c_row0 + (unsigned)rrow;
         const unsigned kb = (unsigned)(p.sc_kb0 + (ocol >> 5));
         *(uint2*)(p.SC + dk_mx_scale_index(r0, kb, (unsigned)p.sc_nblk)) = make_uint2(sc_lo, sc_hi);
       }
     };
-    if (fast)
-      rows(std::true_type{});
-    else
-      rows(std::false_type{});
-  }
+    using Run = std::integral_constant<int, -1>;
+    if (fast) {
+      // the model's combinations with epilogue and output kind folded at compile time (no scalar branches inside the row loop)
+      if (epi == DK_EPI_BIAS && !out_mx8)
+        rows(std::true_type{}, std::integral_constant<int, DK_EPI_BIAS>{}, std::integral_constant<int, 0>{});
+      else if (epi == DK_EPI_BIAS_GELU && out_mx8)
+        rows(std::true_type{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{}, std::integral_constant<int, 1>{});
+      else if (epi == DK_EPI_GATE_RES && !out_mx8)
+        rows(std::true_type{}, std::integral_constant<int, DK_EPI_GATE_RES>{}, std::integral_constant<int, 0>{});
+      else
+        rows(std::true_type{}, Run{}, Run{});
+    } else {
+      rows(std::false_type{}, Run{}, Run{});
+    }
+  };
+  tail_pass(std::integral_constant<int, 0>{});
+  tail_pass(std::integral_constant<int, 1>{});
 }
 
 bool dk_gemm256f8_eligible(const GemmF8Params& p) {

@@ -661,6 +661,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{});
       else if (epi == DK_EPI_GATE_RES)
         rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_GATE_RES>{});
+      else if (epi == DK_EPI_RES)
+        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_RES>{});
       else
         rows(std::true_type{}, std::true_type{}, EkRun{});
     } else if (bf_stage) {
