@@ -67,7 +67,8 @@ extern "C" int dk_gemm_bf16(const dk_gemm_desc* d, void* stream) {
   return dk_launch_gemm(gemm_params_from_desc(d), S_(stream));
 }
 
-extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) {
+// workspace: optional K-split scratch (dk_gemm_split_workspace_bytes) for stages whose tiles fill only half the CUs
+static int conv3x3_launch(const dk_conv_desc* d, void* workspace, hipStream_t stream) {
   DK_REQUIRE(d != nullptr, "null descriptor");
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -79,10 +80,12 @@ extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) {
   p.alpha = 1.0f; p.epi = d->epilogue;
   p.conv = 1; p.cB = d->B; p.cH = d->H; p.cW = d->W; p.cC = d->C; p.ups = d->upsample;
   p.zeros = (const bf16_t*)d->zeros;
+  if (workspace) { p.workspace = workspace; p.workspace_bytes = dk_gemm_split_workspace_bytes(); }
   DK_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "upsample: 0 plain, 1 nearest-x2 input view, 2 stride-2 (downsample)");
   if (d->upsample == 1) DK_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "upsampled conv needs even output size");
-  return dk_launch_gemm(p, S_(stream));
+  return dk_launch_gemm(p, stream);
 }
+extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) { return conv3x3_launch(d, nullptr, S_(stream)); }
 
 extern "C" size_t dk_attention_workspace_bytes(void) { return dk_attention_balance_workspace_bytes(); }
 extern "C" int dk_attention_set_workspace(void* workspace, size_t bytes) {
@@ -269,6 +272,11 @@ static int fuse_q() { return g_dk_fuse_q ? 1 : 0; }
 // (thread_local) -- never share a flag region.  A single engine must not be driven from two streams concurrently (its
 // activations live in one workspace anyway).
 static thread_local void* g_linear_ws = nullptr;
+struct LinearWsScope {  // an engine call's GEMMs split through that engine's region; the previous setting comes back afterwards
+  void* prev;
+  explicit LinearWsScope(void* ws) : prev(g_linear_ws) { g_linear_ws = ws; }
+  ~LinearWsScope() { g_linear_ws = prev; }
+};
 
 static GemmParams linear_params(const bf16_t* A, int lda, int a_seg_len, int a_seg_stride, const bf16_t* W, const bf16_t* bias,
                                 bf16_t* C, int ldc, int c_seg_len, int c_seg_stride, int M, int N, int K, int epi,
@@ -973,6 +981,7 @@ struct dk_vae {
   // workspace views
   bf16_t *bufA, *bufB, *T1, *Y, *SC, *LAT, *ZERO, *Qb, *Kb, *Vb, *Vt, *SCORES;
   float* gn;
+  void* GWS = nullptr;  // GEMM split workspace of this engine's launches (fp32 slabs + flags)
 };
 
 extern "C" int dk_vae_create(const dk_vae_config* cfg, dk_vae** out) {
@@ -1030,6 +1039,7 @@ static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
   v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
   v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
   v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  v->GWS = c.take(dk_gemm_split_workspace_bytes());
   return c.off;
 }
 extern "C" size_t dk_vae_workspace_bytes(const dk_vae* v, int32_t batch, int32_t latent_h, int32_t latent_w) {
@@ -1061,7 +1071,7 @@ struct VaeRun {
     if (rc) return rc;
     d.B = B; d.H = H; d.W = Wd; d.C = C; d.O = O; d.ldy = ldy; d.ldr = O; d.upsample = ups;
     d.epilogue = res ? DK_EPI_RES : DK_EPI_BIAS;
-    return dk_conv3x3_bf16(&d, st);
+    return conv3x3_launch(&d, v->GWS, st);
   }
   // ResnetBlock2D (vae.py:60-101): x [B,H,W,Cin] -> out [B,H,W,Cout]
   int resnet(const bf16_t* x, bf16_t* out, int H, int Wd, int Cin, int Cout, const std::string& p) {
@@ -1124,6 +1134,9 @@ extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int3
   const dk_vae_config& cf = v->cfg;
   VaeRun R{v, S_(stream), batch};
   hipStream_t st = R.st;
+  // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
+  DK_CHECK_HIP(hipMemsetAsync((char*)v->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
+  LinearWsScope ws_scope(v->GWS);
   DK_CHECK_HIP(hipMemsetAsync(v->ZERO, 0, 256, st));
   int H = latent_h, W = latent_w;
   const int Cm = cf.block_out_channels[cf.n_blocks - 1];
@@ -1190,6 +1203,7 @@ static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
   v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
   v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
   v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  v->GWS = c.take(dk_gemm_split_workspace_bytes());
   return c.off;
 }
 extern "C" size_t dk_vae_encoder_workspace_bytes(const dk_vae* v, int32_t batch, int32_t image_h, int32_t image_w) {
@@ -1212,6 +1226,8 @@ extern "C" int dk_vae_encode(dk_vae* v, const float* image, int32_t batch, int32
   DK_REQUIRE(need_bytes <= workspace_bytes, "workspace too small");
   VaeRun R{v, S_(stream), batch};
   hipStream_t st = R.st;
+  DK_CHECK_HIP(hipMemsetAsync((char*)v->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
+  LinearWsScope ws_scope(v->GWS);
   DK_CHECK_HIP(hipMemsetAsync(v->ZERO, 0, 256, st));
   int H = image_h, W = image_w;
   DK_TRY(dk_launch_pad_channels(image, v->LAT, (long)batch * H * W, cf.in_channels, 64, st));

@@ -258,7 +258,8 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     // implicit-GEMM convolutions with O % 256 == 0 ride the 256^2 kernel once their tiles fill most of the CUs (the VAE's 256^2-pixel
     // and larger stages); the 128^2-tile kernel below keeps the small stages and O = 128
     const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
-    if (g_dk_gemm_mode == 9 || t256 >= 192) return dk_launch_gemm256v3(p, nullptr, stream);
+    // (with the K-split workspace a stage of about half the CUs' worth of tiles goes there too: its tiles are cut in two along K)
+    if (g_dk_gemm_mode == 9 || t256 >= 192 || (p.workspace != nullptr && t256 >= 96 && t256 <= 128)) return dk_launch_gemm256v3(p, nullptr, stream);
   }
   DK_REQUIRE(p.K % BK == 0, "K must be a multiple of 64");
   DK_REQUIRE(p.ldc % 4 == 0, "ldc must be a multiple of 4 elements");
