@@ -427,7 +427,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
         unpack8(make_uint4(sv[0], sv[1], sv[2], sv[3]), vv);
         if (ep == DK_EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) vv[e] = gelu_erf_f(vv[e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 g2 = gelu_erf_f2(f32x2{vv[e], vv[e + 1]});
+            vv[e] = g2[0], vv[e + 1] = g2[1];
+          }
         } else if (ep == DK_EPI_BIAS_SILU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);

@@ -16,6 +16,7 @@ if os.environ.get("SWEEP"):  # per-round fixed cost: the same 768 tiles (3 round
     shapes = [(f"N12288 K{k}", 4096, 12288, k) for k in (512, 1024, 2048, 3072, 6144)] + [(f"N3072 K{k}", 4352, 3072, k) for k in (1024, 3072, 6144, 15360)]
 g = torch.Generator(device=dev).manual_seed(0)
 ncopy = int(os.environ.get("COLD_W", "1"))
+epi = {"bias": ops.DK_EPI_BIAS, "gelu": ops.DK_EPI_BIAS_GELU}[os.environ.get("EPI", "bias")]
 out = []
 for name, M, N, K in shapes:
     x = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
@@ -26,13 +27,13 @@ for name, M, N, K in shapes:
     best = 1e9
     for rnd in range(3):
         for i in range(3):
-            ops.linear(x, wlist[i % ncopy], b, out=y)
+            ops.linear(x, wlist[i % ncopy], b, out=y, epilogue=epi)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(24):
-            ops.linear(x, wlist[i % ncopy], b, out=y)
+            ops.linear(x, wlist[i % ncopy], b, out=y, epilogue=epi)
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 24)
     out.append(f"{name} {M}x{N}x{K}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF")
-print(os.environ.get("DK_HIP_LIB", "default lib"), "COLD_W=" + os.environ.get("COLD_W", "1"), " | ".join(out), flush=True)
+print(os.environ.get("DK_HIP_LIB", "default lib"), "EPI=" + os.environ.get("EPI", "bias"), "COLD_W=" + os.environ.get("COLD_W", "1"), " | ".join(out), flush=True)
