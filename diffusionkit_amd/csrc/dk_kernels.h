@@ -41,6 +41,15 @@ struct GemmParams {
   bf16_t* C2;
   int ldc2;
   int epi2;
+  // optional QKNorm + RoPE of the KEY columns (mmdit.py:754-764, 934-942) inside the tail of a q / k / v projection on the 256^2
+  // kernel (bias-only epilogue): columns [kn_col0, kn_col1) -- multiples of 256 -- are heads of kn_D (128 or 64) columns; a row's
+  // head is normalised with weight kn_w [kn_D] and rotated by the cos / sin table kn_rope [S_pos, kn_D / 2, 2] (null: no rotation)
+  // at position kn_pos_off + (row % kn_seg_len).  Same arithmetic and rounding points as dk_qk_norm_rope_kernel.  Null kn_w: off.
+  // (a launch that does not reach the 256^2 kernel runs dk_launch_qk_norm_rope on its output instead: gemm.hip)
+  const bf16_t* kn_w;
+  const float* kn_rope;
+  int kn_col0, kn_col1, kn_D, kn_pos_off, kn_seg_len;
+  float kn_eps;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
 extern int g_dk_gemm_mode;
@@ -85,6 +94,11 @@ struct GemmF8Params {
   // addresses, and the 32-column block index of output column 0 inside that buffer's rows
   unsigned char* SC;
   int sc_nblk, c_row0, sc_kb0;
+  // optional QKNorm + RoPE of the key columns in the tail (see GemmParams; bf16 first output, bias-only epilogue)
+  const bf16_t* kn_w;
+  const float* kn_rope;
+  int kn_col0, kn_col1, kn_D, kn_pos_off, kn_seg_len;
+  float kn_eps;
 };
 bool dk_gemm256f8_eligible(const GemmF8Params& p);
 int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream_t stream);

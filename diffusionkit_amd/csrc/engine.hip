@@ -19,6 +19,7 @@ extern "C" int dk_abi_version(void) { return DK_ABI_VERSION; }
 extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
 
 int g_dk_attn_mode = -1;
+int g_dk_fuse_k = 1;  // dk_tune_set("gemm_fuse_k", v): QKNorm + RoPE of the keys inside the q / k / v projection's tail (1, default) or as a separate pass (0)
 int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the queries inside the attention kernel's Q load (1, default) or as a separate pass (0)
 // Rows of K >= g_dk_pitch_min_k elements (the [h, 5h] linear2 and [h, 4h] fc2 weights of FLUX and the activations they
 // multiply) are stored with 64 elements of padding: a 24-30 KB row stride makes the K-tile DMA of 256 rows camp on a few
@@ -31,6 +32,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "attn_balance") == 0) { g_dk_attn_balance = value; return 0; }
+  if (strcmp(key, "gemm_fuse_k") == 0) { g_dk_fuse_k = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
@@ -265,6 +267,13 @@ struct Carver {
 
 // every attention kernel can normalise / rotate the queries in its Q load
 static int fuse_q() { return g_dk_fuse_q ? 1 : 0; }
+// the keys' QKNorm + RoPE rides in the q / k / v projection's tail (only together with the fused query side: the stand-alone pass
+// then has nothing left to do)
+static bool fuse_k(const bf16_t* kn) { return g_dk_fuse_k != 0 && fuse_q() && kn != nullptr; }
+template <typename P>
+static void set_key_norm(P& p, const bf16_t* kn, int h, int D, const float* rope, int pos_off, int seg_len) {
+  p.kn_w = kn; p.kn_rope = rope; p.kn_col0 = h; p.kn_col1 = 2 * h; p.kn_D = D; p.kn_pos_off = pos_off; p.kn_seg_len = seg_len; p.kn_eps = 1e-6f;
+}
 
 // Split workspace (fp32 slabs + flags) handed to the GEMMs an engine call builds: every dk_mmdit_* entry point sets it to ITS
 // engine's region (carved from that engine's workspace) before it enqueues anything and all launches of the call are
@@ -750,10 +759,15 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
       GemmF8Params qt = f8_params(m, m->XN8, m->SXN, h, Mi, Mt, 0, wt.qkv_w8, h, wt.qkv_ws, wt.qkv_b, Mt, 3 * h, h, DK_EPI_BIAS);
       f8_out_bf16(qi, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S);
       f8_out_bf16(qt, m->QKV, 3 * h, S_t, S);
+      if (fuse_k(wi.kn) && fuse_k(wt.kn)) {
+        set_key_norm(qi, wi.kn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
+        set_key_norm(qt, wt.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
+      }
       DK_TRY(f8_pair(qi, &qt, st));
     }
-    DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
-                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
+    if (!(fuse_k(wi.kn) && fuse_k(wt.kn)))
+      DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
+                                     c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
@@ -814,10 +828,12 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
       f8_out_bf16(l1, m->QKV, 3 * h, M, 0);
       l1.n_split = 3 * h; l1.C2 = m->HC8 + h; l1.ldc2 = ldcat8; l1.epi2 = DK_EPI_BIAS_GELU; l1.c2_mx8 = 1;
       l1.SC = m->SCAT; l1.sc_nblk = m->nblk; l1.c_row0 = 0; l1.sc_kb0 = h / 32;
+      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
       DK_TRY(f8_pair(l1, nullptr, st));
     }
-    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr, S, S, 0, S,
-                                  st, fuse_q()));
+    if (!fuse_k(w.kn))
+      DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr, S, S, 0, S,
+                                    st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
@@ -890,15 +906,20 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
     // (image and text stream of each elementwise stage in ONE launch: the 256 text rows do not run alone on the chip)
     DK_TRY(dk_launch_ln_modulate2(X_img, XN_img, Mi, mod_img, mod_img + h, S_i, X_txt, XN_txt, Mt, mod_txt, mod_txt + h, S_t, h, h, h,
                                   mod_stride, S, c.layer_norm_eps, st));
-    DK_TRY(dk_launch_gemm_pair(
-        linear_params(XN_img, h, Mi, 0, wi.qkv_w, wi.qkv_b, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S, Mi, 3 * h, h, DK_EPI_BIAS, nullptr,
-                      0, 0, nullptr, 0, 0, 0),
-        linear_params(XN_txt, h, Mt, 0, wt.qkv_w, wt.qkv_b, m->QKV, 3 * h, S_t, S, Mt, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0,
-                      0, 0),
-        st));
-    // QKNorm + RoPE: the keys in one pass over the buffer, the queries inside the attention kernel's Q load
-    DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
-                                   c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
+    GemmParams qkv_img = linear_params(XN_img, h, Mi, 0, wi.qkv_w, wi.qkv_b, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S, Mi, 3 * h, h, DK_EPI_BIAS,
+                                       nullptr, 0, 0, nullptr, 0, 0, 0);
+    GemmParams qkv_txt = linear_params(XN_txt, h, Mt, 0, wt.qkv_w, wt.qkv_b, m->QKV, 3 * h, S_t, S, Mt, 3 * h, h, DK_EPI_BIAS, nullptr, 0, 0,
+                                       nullptr, 0, 0, 0);
+    // QKNorm + RoPE: the keys in the projection's tail (or one pass over the buffer), the queries inside the attention kernel's Q load
+    const bool kf = fuse_k(wi.kn) && fuse_k(wt.kn);
+    if (kf) {
+      set_key_norm(qkv_img, wi.kn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
+      set_key_norm(qkv_txt, wt.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
+    }
+    DK_TRY(dk_launch_gemm_pair(qkv_img, qkv_txt, st));
+    if (!kf)
+      DK_TRY(dk_launch_qk_norm_rope2(m->QKV + (size_t)S_t * 3 * h, Mi, wi.qn, wi.kn, S_i, S_t, m->QKV, Mt, wt.qn, wt.kn, S_t, 0, 3 * h, 0, h,
+                                     c.num_heads, m->D(), 1e-6f, c.use_rope ? m->rope : nullptr, S, st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
@@ -950,10 +971,12 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
       GemmParams l1 = linear_params(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, (3 + r) * h, h, DK_EPI_BIAS, nullptr, 0, 0,
                                     nullptr, 0, 0, 0);
       l1.n_split = 3 * h; l1.C2 = m->CAT + h; l1.ldc2 = ldcat; l1.epi2 = DK_EPI_BIAS_GELU;
+      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
       DK_TRY(dk_launch_gemm(l1, st));
     }
-    DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
-                                  S, S, 0, S, st, fuse_q()));
+    if (!fuse_k(w.kn))
+      DK_TRY(dk_launch_qk_norm_rope(m->QKV, 3 * h, 0, h, M, c.num_heads, m->D(), w.qn, w.kn, 1e-6f, c.use_rope ? m->rope : nullptr,
+                                    S, S, 0, S, st, fuse_q()));
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->CAT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = ldcat; ap.scale = scale;

@@ -244,6 +244,17 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9);
   if (g_dk_gemm_mode == 9 && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
   if (big) return dk_launch_gemm256v3(p, nullptr, stream);
+  if (p.kn_w != nullptr) {
+    // the fused key QKNorm + RoPE lives in the 256^2 kernel's tail: any other route runs the projection plain and the
+    // stand-alone pass over its key columns afterwards
+    GemmParams plain = p;
+    plain.kn_w = nullptr;
+    const int rc = dk_launch_gemm(plain, stream);
+    if (rc) return rc;
+    DK_REQUIRE(p.c_seg_len == p.kn_seg_len || p.c_seg_len >= p.M, "fused key QKNorm: the output's row segments must be the sequences");
+    return dk_launch_qk_norm_rope(p.C, p.ldc, 0, p.kn_col0, p.M, (p.kn_col1 - p.kn_col0) / p.kn_D, p.kn_D, p.kn_w, p.kn_w, p.kn_eps, p.kn_rope,
+                                  p.kn_seg_len, p.c_seg_len == p.kn_seg_len ? p.c_seg_stride : p.kn_seg_len, p.kn_pos_off, 0, stream, 1);
+  }
   if (p.n_split > 0) {
     // column-split GEMM on the kernel without split support: two GEMMs over the two column ranges
     DK_REQUIRE(p.n_split < p.N && p.C2 != nullptr, "bad column split");

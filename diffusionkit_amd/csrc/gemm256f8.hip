@@ -360,6 +360,32 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     ws_q[nf] = *(const f32x4*)(p.wscale + n0 + wn * 64 + nf * 16 + 4 * q);
     if (p.bias) bias_q[nf] = *(const u32x2*)(p.bias + n0 + wn * 64 + nf * 16 + 4 * q);
   }
+  // Key tile of a q / k / v projection with the fused QKNorm + RoPE (gemm256v3.hip has the bf16 twin): the sum of squares of every
+  // row over its head's columns -- this wave's 64 columns from the accumulators, for 128-column heads plus the partner wave's
+  // through LDS (behind the staging images)
+  const bool kfuse = p.kn_w != nullptr && !out2 && n0 >= p.kn_col0 && n0 < p.kn_col1;  // tile-uniform
+  constexpr unsigned XCH_OFF = 8u * 16384u;
+  if (kfuse) {
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+      float ss = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        float b4[4];
+        unpack2bf(bias_q[nf][0], b4[0], b4[1]);
+        unpack2bf(bias_q[nf][1], b4[2], b4[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = round_bf16(acc[nf][mf][e] * ws_q[nf][e] + b4[e]);
+          ss += v * v;
+        }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (q == 0) *(__attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + (wave * 128 + mf * 16 + l15) * 4) = ss;
+    }
+    __syncthreads();
+  }
   // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
   auto tail_pass = [&](auto ni_c) {
     constexpr int ni = decltype(ni_c)::value;
@@ -383,8 +409,12 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
     const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (gate, residual)
     const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
     float gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto rows = [&](auto fast_c, auto ek_c, auto mx_c) {
+    auto rows = [&](auto fast_c, auto ek_c, auto mx_c, auto kf_c) {
       constexpr bool FAST = decltype(fast_c)::value;
+      constexpr bool KF = decltype(kf_c)::value;  // key tile with the fused QKNorm + RoPE (bias-only epilogue, bf16 out)
+      float kw8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int kcol = KF ? (col - p.kn_col0) % p.kn_D : 0;  // first of this lane's 8 columns inside its head
+      if (KF) unpack8(*(const uint4*)(p.kn_w + kcol), kw8);
       constexpr int EK = decltype(ek_c)::value;  // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
       constexpr int MX = decltype(mx_c)::value;  // output: 1 MX-fp8, 0 bf16, -1: `out_mx8`
       const int ep = EK >= 0 ? EK : epi;
@@ -419,12 +449,32 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
             for (g_rem += 16; g_rem >= p.gate_seg_len; g_rem -= p.gate_seg_len) ++g_seg;
         }
         const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
-        if (EK == DK_EPI_BIAS && MX == 0) {  // bias only, bf16 out: the staged values ARE the output
+        if (EK == DK_EPI_BIAS && MX == 0 && !KF) {  // bias only, bf16 out: the staged values ARE the output
           if (FAST || valid) *(u32x4*)((bf16_t*)Cb + crow * (size_t)ldcb + ocol) = sv;
           continue;
         }
         float vv[8];
         unpack8(make_uint4(sv[0], sv[1], sv[2], sv[3]), vv);
+        if (KF) {
+          const int kpos = (mrow0 + row) % p.kn_seg_len;  // the row's position inside its sequence
+          float ss = *(const __attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + (wave * 128 + row) * 4);
+          if (p.kn_D == 128) ss += *(const __attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + ((wave ^ 1) * 128 + row) * 4);
+          const float r = rsqrtf(ss / (float)p.kn_D + p.kn_eps);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = round_bf16(vv[e] * r * kw8[e]);
+          if (p.kn_rope != nullptr) {
+            const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
+            f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+            if (FAST || valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
+            const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float c = cs[2 * i], sn = cs[2 * i + 1], xe = vv[2 * i], xo = vv[2 * i + 1];
+              vv[2 * i] = c * xe - sn * xo;
+              vv[2 * i + 1] = sn * xe + c * xo;
+            }
+          }
+        }
         if (ep == DK_EPI_BIAS_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
@@ -478,18 +528,25 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
       }
     };
     using Run = std::integral_constant<int, -1>;
-    if (fast) {
+    using No = std::false_type;
+    using Yes = std::true_type;
+    if (kfuse) {  // (bias-only epilogue, bf16 out -- checked by the launcher)
+      if (fast)
+        rows(Yes{}, std::integral_constant<int, DK_EPI_BIAS>{}, std::integral_constant<int, 0>{}, Yes{});
+      else
+        rows(No{}, std::integral_constant<int, DK_EPI_BIAS>{}, std::integral_constant<int, 0>{}, Yes{});
+    } else if (fast) {
       // the model's combinations with epilogue and output kind folded at compile time (no scalar branches inside the row loop)
       if (epi == DK_EPI_BIAS && !out_mx8)
-        rows(std::true_type{}, std::integral_constant<int, DK_EPI_BIAS>{}, std::integral_constant<int, 0>{});
+        rows(Yes{}, std::integral_constant<int, DK_EPI_BIAS>{}, std::integral_constant<int, 0>{}, No{});
       else if (epi == DK_EPI_BIAS_GELU && out_mx8)
-        rows(std::true_type{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{}, std::integral_constant<int, 1>{});
+        rows(Yes{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{}, std::integral_constant<int, 1>{}, No{});
       else if (epi == DK_EPI_GATE_RES && !out_mx8)
-        rows(std::true_type{}, std::integral_constant<int, DK_EPI_GATE_RES>{}, std::integral_constant<int, 0>{});
+        rows(Yes{}, std::integral_constant<int, DK_EPI_GATE_RES>{}, std::integral_constant<int, 0>{}, No{});
       else
-        rows(std::true_type{}, Run{}, Run{});
+        rows(Yes{}, Run{}, Run{}, No{});
     } else {
-      rows(std::false_type{}, Run{}, Run{});
+      rows(No{}, Run{}, Run{}, No{});
     }
   };
   tail_pass(std::integral_constant<int, 0>{});
@@ -507,6 +564,11 @@ bool dk_gemm256f8_eligible(const GemmF8Params& p) {
   const bool res2 = p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES);
   if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 8 != 0)) return false;
   if ((p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES)) && (p.gate == nullptr || p.gate_seg_len <= 0)) return false;
+  if (p.kn_w != nullptr) {  // fused key QKNorm + RoPE: whole 256-column tiles of 128- or 64-column heads, bias-only bf16 first output
+    if (p.epi != DK_EPI_BIAS || p.c_mx8 || (p.kn_D != 128 && p.kn_D != 64) || p.kn_seg_len <= 0 || p.kn_col0 % 256 != 0 || p.kn_col1 % 256 != 0 ||
+        p.kn_col0 >= p.kn_col1 || p.kn_col1 > (p.n_split > 0 ? p.n_split : p.N) || ((uintptr_t)p.kn_w & 15) != 0 || ((uintptr_t)p.kn_rope & 15) != 0)
+      return false;
+  }
   // outputs: bf16 rows of 16-byte stores, or MX-fp8 rows of 8-byte stores with the scale side array
   auto al = [](const void* q, int a) { return ((uintptr_t)q & (uintptr_t)(a - 1)) == 0; };
   if (p.c_mx8 ? (p.ldc % 8 != 0 || !al(p.C, 8)) : (p.ldc % 8 != 0 || !al(p.C, 16))) return false;

@@ -508,6 +508,32 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) bias_q[nf] = *(const u32x2*)(p.bias + n0 + wn * 64 + nf * 16 + 4 * q);
   }
+  // Key tile of a q / k / v projection with the fused QKNorm + RoPE: the sum of squares of every row over its head's columns --
+  // this wave's 64 columns from the accumulators (same bf16-rounded values that get staged), for 128-column heads plus the
+  // partner wave's 64 through LDS (behind the staging images)
+  const bool kfuse = !CONV && p.kn_w != nullptr && piece < 0 && n0 >= p.kn_col0 && n0 < p.kn_col1;  // tile-uniform
+  constexpr unsigned XCH_OFF = 8u * 16384u;
+  if (kfuse) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float ss = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        float b4[4];
+        unpack2bf(bias_q[nf][0], b4[0], b4[1]);
+        unpack2bf(bias_q[nf][1], b4[2], b4[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = round_bf16(acc[nf][mf][e] * p.alpha + b4[e]);
+          ss += v * v;
+        }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (q == 0) *(__attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + (wave * 128 + mf * 16 + l15) * 4) = ss;
+    }
+    __syncthreads();
+  }
   // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
   auto tail_pass = [&](auto ni_c) {
     constexpr int ni = decltype(ni_c)::value;
@@ -548,11 +574,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     if (p.bias && piece == 0) unpack8(*(const uint4*)(p.bias + col), bias8);  // (whole tiles: the bias went in before staging)
     // the row loop is instantiated twice -- tile-uniform maps (FAST) or a per-lane walk through the maps -- so that
     // the common case keeps its short body (one v_add per address, batched loads)
-    auto rows = [&](auto fast_c, auto bf_c, auto ek_c) {
+    auto rows = [&](auto fast_c, auto bf_c, auto ek_c, auto kf_c) {
       constexpr bool FAST = decltype(fast_c)::value;
+      constexpr bool KF = decltype(kf_c)::value;  // key tile with the fused QKNorm + RoPE (bf16 image, bias-only epilogue)
       constexpr bool BF = decltype(bf_c)::value;  // bf16 image of a whole tile / fp32 image of a split tile
       constexpr int EK = decltype(ek_c)::value;   // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
-      constexpr bool PLAIN = BF && EK == DK_EPI_BIAS;  // a bias-only epilogue on a bf16 image: the staged values ARE the output
+      constexpr bool PLAIN = BF && EK == DK_EPI_BIAS && !KF;  // a bias-only epilogue on a bf16 image: the staged values ARE the output
+      float kw8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int kcol = KF ? (col - p.kn_col0) % p.kn_D : 0;  // first of this lane's 8 columns inside its head
+      if (KF) unpack8(*(const uint4*)(p.kn_w + kcol), kw8);
       const int ep = EK >= 0 ? EK : epi;
       const bool hres = EK >= 0 ? (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES) : has_res;
       if (FAST && ep == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
@@ -569,6 +599,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         const int row = itr * 16 + rrow;  // row inside the wave's block of HROWS rows
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
         bool valid = true;
+        const int kpos = KF ? (mrow0 + row) % p.kn_seg_len : 0;  // the row's position inside its sequence
         if (!FAST) {
           valid = mrow0 + row < p.M;
           crow = (size_t)c_seg * p.c_seg_stride + c_rem;
@@ -617,6 +648,25 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
             vv[4 + e] = round_bf16(a1[e] * p.alpha + bias8[4 + e]);
           }
         }
+        if (KF) {
+          float ss = *(const __attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + (wave * 128 + row) * 4);
+          if (p.kn_D == 128) ss += *(const __attribute__((address_space(3))) float*)((lds_char*)0 + XCH_OFF + ((wave ^ 1) * 128 + row) * 4);
+          const float r = rsqrtf(ss / (float)p.kn_D + p.kn_eps);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = round_bf16(vv[e] * r * kw8[e]);
+          if (p.kn_rope != nullptr) {
+            const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
+            f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+            if (FAST || valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
+            const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float c = cs[2 * i], sn = cs[2 * i + 1], xe = vv[2 * i], xo = vv[2 * i + 1];
+              vv[2 * i] = c * xe - sn * xo;
+              vv[2 * i + 1] = sn * xe + c * xo;
+            }
+          }
+        }
         if (ep == DK_EPI_BIAS_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
@@ -656,25 +706,32 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       }
     };
     using EkRun = std::integral_constant<int, -1>;
-    if (bf_stage && fast) {
+    using No = std::false_type;
+    using Yes = std::true_type;
+    if (kfuse) {  // (whole tile, bias-only epilogue -- checked by the launcher)
+      if (fast)
+        rows(Yes{}, Yes{}, std::integral_constant<int, DK_EPI_BIAS>{}, Yes{});
+      else
+        rows(No{}, Yes{}, std::integral_constant<int, DK_EPI_BIAS>{}, Yes{});
+    } else if (bf_stage && fast) {
       // the common epilogues with the epilogue folded at compile time (no scalar branches inside the row loop)
       if (epi == DK_EPI_BIAS)
-        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_BIAS>{});
+        rows(Yes{}, Yes{}, std::integral_constant<int, DK_EPI_BIAS>{}, No{});
       else if (epi == DK_EPI_BIAS_GELU)
-        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{});
+        rows(Yes{}, Yes{}, std::integral_constant<int, DK_EPI_BIAS_GELU>{}, No{});
       else if (epi == DK_EPI_GATE_RES)
-        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_GATE_RES>{});
+        rows(Yes{}, Yes{}, std::integral_constant<int, DK_EPI_GATE_RES>{}, No{});
       else if (epi == DK_EPI_RES)
-        rows(std::true_type{}, std::true_type{}, std::integral_constant<int, DK_EPI_RES>{});
+        rows(Yes{}, Yes{}, std::integral_constant<int, DK_EPI_RES>{}, No{});
       else
-        rows(std::true_type{}, std::true_type{}, EkRun{});
+        rows(Yes{}, Yes{}, EkRun{}, No{});
     } else if (bf_stage) {
-      rows(std::false_type{}, std::true_type{}, EkRun{});
+      rows(No{}, Yes{}, EkRun{}, No{});
     } else {
       if (fast)
-        rows(std::true_type{}, std::false_type{}, EkRun{});
+        rows(Yes{}, No{}, EkRun{}, No{});
       else
-        rows(std::false_type{}, std::false_type{}, EkRun{});
+        rows(No{}, No{}, EkRun{}, No{});
     }
   };
   if (!((DK_V3_ABL & 64) && p.alpha != -1234.5f)) {  // (lab: 64 = no tail at run time)
@@ -705,6 +762,11 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
   const bool res2 = p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES);
   if ((res1 || res2) && (p.res == nullptr || p.r_seg_len <= 0 || p.ldr % 8 != 0)) return false;
   if ((p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES)) && (p.gate == nullptr || p.gate_seg_len <= 0)) return false;
+  if (p.kn_w != nullptr) {  // fused key QKNorm + RoPE: whole 256-column tiles of 128- or 64-column heads, bias-only first output
+    if (p.conv || p.epi != DK_EPI_BIAS || (p.kn_D != 128 && p.kn_D != 64) || p.kn_seg_len <= 0 || p.kn_col0 % 256 != 0 || p.kn_col1 % 256 != 0 || p.kn_col0 >= p.kn_col1 ||
+        p.kn_col1 > (p.n_split > 0 ? p.n_split : p.N) || ((uintptr_t)p.kn_w & 15) != 0 || ((uintptr_t)p.kn_rope & 15) != 0)
+      return false;
+  }
   // 16-byte accesses in the tail
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(p.C) || !al16(p.C2) || !al16(p.res) || !al16(p.bias) || !al16(p.gate) || (p.gate != nullptr && p.gate_stride % 8 != 0)) return false;
@@ -793,7 +855,9 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   const int bm = 32 * mf;
   const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / T256);
   const int tiles_b = two ? ((pb.M + bm - 1) / bm) * (pb.N / T256) : 0;
-  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0;
+  // (a launch with the fused key QKNorm is never split: a split tile's finisher has no second pass over its row sums)
+  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0 &&
+                       p.kn_w == nullptr && (!two || pb.kn_w == nullptr);
   const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
   SplitArgs sp;
   memset(&sp, 0, sizeof(sp));

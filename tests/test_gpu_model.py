@@ -298,6 +298,38 @@ def test_flux_width_block_pair_full_sequence(dev):
     psnr_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], "flux width")
 
 
+@pytest.mark.parametrize("B,mf", [(1, -1), (2, 8), (2, 7)])
+def test_fused_key_norm_matches_separate_pass(dev, B, mf):
+    """QKNorm + RoPE of the keys inside the q / k / v projection's tail (dk_tune_set("gemm_fuse_k", 1), default) against the
+    stand-alone pass over the projection's output (0): FLUX geometry, depth 1+1 -- double block (two streams, own weights and
+    positions) and single block (column-split linear1); two images: rows of both sequences inside one launch, with 224-row tiles
+    straddling the sequence boundary.  Same values up to the summation order of a head's squares."""
+    from dataclasses import replace
+    from diffusionkit_amd import ops
+    cfg = replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1)
+    eng, _ = build(cfg, dev)
+    text = randn(B, 256, cfg.token_level_text_embed_dim, seed=3)
+    pooled = randn(B, cfg.pooled_text_embed_dim, seed=4)
+    lat = randn(B, 128, 128, 16, seed=5)
+    eng.prepare(B, (128, 128), 256, 2)
+    eng.cache_modulation_params(pooled.to(dev), [1000.0, 752.0])
+    tok = eng.patchify(lat.to(dev))
+    outs = {}
+    try:
+        ops.tune("gemm_mf", mf)
+        for fuse in (1, 0):
+            ops.tune("gemm_fuse_k", fuse)
+            outs[fuse] = eng.forward_tokens(tok, text.to(dev, BF), 1).float().cpu()
+    finally:
+        ops.tune("gemm_fuse_k", 1)
+        ops.tune("gemm_mf", -1)
+    d = (outs[1] - outs[0]).abs()
+    assert torch.isfinite(outs[1]).all()
+    # (a key that lands one bf16 ulp away moves its whole score column: 3e-3 after the two blocks)
+    assert rel_l2(outs[0], outs[1]) < 8e-3, float(rel_l2(outs[0], outs[1]))
+    assert float(d.max()) <= 0.05 * float(outs[0].abs().max())
+
+
 def test_sd3_width_cfg_batch(dev):
     """SD3-medium geometry (h 1536, 24 heads, D 64, learned pos-emb, conv patchify), CFG batch 2,
     latent 64x64 (BASELINE config #1 size), S_t = 154, depth 2."""
