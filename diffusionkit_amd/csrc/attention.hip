@@ -47,5 +47,10 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   dk_prof_end(stream);
   if (rc) return rc;
   DK_CHECK_HIP(hipGetLastError());
+  if (p.O8 != nullptr && mode != 7 && mode != 8) {
+    // only the pipelined kernel writes the MX-fp8 copy itself: quantise the bf16 output behind the others
+    Mx8Out o8{p.O8, p.O8_scales, p.o8_ld, p.o8_nblk, 0, p.B * p.S, 0, 0};
+    return dk_launch_quantize_mx8(p.O, p.ldo, p.B * p.S, 0, p.B * p.S, p.H * p.D, o8, stream);
+  }
   return 0;
 }

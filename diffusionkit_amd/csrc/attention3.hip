@@ -402,7 +402,35 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
     const float lsum = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / lsum;
     const int q = q0 + l31;
-    if (q < S) {
+    if (p.O8 != nullptr) {
+      // MX-fp8 output: a 32-column block (one dt) of a query row lives in this lane and lane ^ 32 (16 values each)
+      const size_t orow = (size_t)b * S + min(q, S - 1);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+        float v[16], amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = round_bf16(o[dt][e] * inv);
+          amax = fmaxf(amax, fabsf(v[e]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const float t = amax * (1.0f / 448.0f);
+        unsigned e8 = (__float_as_uint(t) + 0x7FFFFFu) >> 23;  // ceil(log2 t) + 127 (dk_mx8_quantize8)
+        e8 = e8 < 1u ? 1u : (e8 > 254u ? 254u : e8);
+        const float sc = __uint_as_float((254u - e8) << 23);
+        if (q < S) {
+          unsigned char* orow8 = p.O8 + orow * (size_t)p.o8_ld + head * D + dt * 32 + 4 * hi;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g4 + 0] * sc, v[4 * g4 + 1] * sc, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g4 + 2] * sc, v[4 * g4 + 3] * sc, w, true);
+            *(int*)(orow8 + 8 * g4) = w;
+          }
+          if (hi == 0) p.O8_scales[dk_mx_scale_index((unsigned)orow, (unsigned)(head * (D / 32) + dt), (unsigned)p.o8_nblk)] = (unsigned char)e8;
+        }
+      }
+    } else if (q < S) {
       bf16_t* op = p.O + ((size_t)b * S + q) * p.ldo + head * D;
 #pragma unroll
       for (int dt = 0; dt < D / 32; ++dt)

@@ -147,6 +147,13 @@ struct AttnParams {
   // bytes = one slot per CU, then 4 KiB of flags that are zero before the first launch (the kernels leave them zero)
   void* bal_ws = nullptr;
   unsigned* bal_flags = nullptr;
+  // optional MX-fp8 copy of the output (fp8_linears: the o-projection's activation operand): row (b*S + s) of O8 at o8_ld bytes
+  // per row, head h at byte column h*D; E8M0 scales of 32-column blocks in O8_scales (dk_mx_scale_index over o8_nblk 128-row
+  // blocks).  dk_attn3_fwd_kernel writes it INSTEAD of O from its accumulators (values rounded to bf16 first, as the separate
+  // quantiser pass over O sees them); for the other kernels dk_launch_attention runs that pass behind the launch.
+  unsigned char* O8 = nullptr;
+  unsigned char* O8_scales = nullptr;
+  int o8_ld = 0, o8_nblk = 0;
 };
 size_t dk_attention_balance_workspace_bytes();
 void dk_set_attention_workspace(void* ws);  // attention.hip: thread-local, picked up by dk_launch_attention

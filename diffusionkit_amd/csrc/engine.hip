@@ -772,8 +772,9 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
     if (fuse_q()) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    // the o-projection's MX-fp8 operand comes out of the attention kernel (or out of a quantiser pass behind it: attention.hip)
+    ap.O8 = m->ATT8; ap.O8_scales = m->SATT; ap.o8_ld = h; ap.o8_nblk = m->nblk;
     DK_TRY(dk_launch_attention(ap, st));
-    DK_TRY(dk_launch_quantize_mx8(m->ATT, h, (int)BS, 0, (int)BS, h, mx8_out(m->ATT8, m->SATT, h, BS, 0, (int)BS, 0, 0), st));
     // post_sdpa (mmdit.py:537-548): residual += gate_attn * o_proj(attn)
     {
       GemmF8Params oi = f8_params(m, m->ATT8, m->SATT, h, S_t, S_i, S, wi.o_w8, h, wi.o_ws, wi.o_b, Mi, h, h, DK_EPI_GATE_RES);
@@ -838,8 +839,8 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
     if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    ap.O8 = m->HC8; ap.O8_scales = m->SCAT; ap.o8_ld = ldcat8; ap.o8_nblk = m->nblk;  // [attn | gelu] operand of linear2: columns [0, h)
     DK_TRY(dk_launch_attention(ap, st));
-    DK_TRY(dk_launch_quantize_mx8(m->ATT, h, M, 0, M, h, mx8_out(m->HC8, m->SCAT, ldcat8, BS, 0, M, 0, 0), st));
     {  // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
       GemmF8Params l2 = f8_params(m, m->HC8, m->SCAT, ldcat8, 0, M, 0, w.l2_w8, ldcat8, w.l2_ws, w.l2_b, M, h, (1 + r) * h, DK_EPI_GATE_RES);
       f8_out_bf16(l2, m->X, h, M, 0);
