@@ -535,14 +535,19 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     __syncthreads();
   }
   // the two 32-column halves of the wave tile (compile-time index: the accumulators must stay in registers)
-  auto tail_pass = [&](auto ni_c) {
+  // (STAGE / EMIT: a whole tile stages BOTH halves -- two 8 KiB bf16 images per wave -- before it reads the first one back: one
+  //  LDS round trip of latency per tile instead of two; a split tile's 16 KiB fp32 image holds one half at a time)
+  auto tail_pass = [&](auto ni_c, auto stage_c, auto emit_c) {
     constexpr int ni = decltype(ni_c)::value;
+    constexpr bool STAGE = decltype(stage_c)::value, EMIT = decltype(emit_c)::value;
+    const unsigned reg0 = (unsigned)wave * 16384u + ((STAGE && EMIT) ? 0u : (unsigned)ni * 8192u);  // this pass's image
     // stage: lane owns row mf*16 + l15, columns (nf & 1)*16 + 4*q + {0..3} of this 32-column half.  A whole tile (no K split)
     // stages round_bf16(alpha * acc + bias) -- what every epilogue starts from -- as bf16: half the LDS bytes of the fp32 image
     // (64-byte rows, 16-byte chunk c at position c ^ ((row >> 2) & 3): conflict-free for these 8-byte writes and the 16-byte
     // read-back); split tiles stage the fp32 partial sums (128-byte rows)
     const bool bf_stage = piece < 0;
-    if (bf_stage) {
+    if (!STAGE) {
+    } else if (bf_stage) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         float b4[4];
@@ -568,6 +573,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         }
     }
     // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
+    if (!EMIT) return;
     const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual)
     const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -735,8 +741,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     }
   };
   if (!((DK_V3_ABL & 64) && p.alpha != -1234.5f)) {  // (lab: 64 = no tail at run time)
-    tail_pass(std::integral_constant<int, 0>{});
-    tail_pass(std::integral_constant<int, 1>{});
+    if (piece < 0) {
+      tail_pass(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
+      tail_pass(std::integral_constant<int, 1>{}, std::true_type{}, std::false_type{});
+      tail_pass(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+      tail_pass(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+    } else {
+      tail_pass(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+      tail_pass(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{});
+    }
   }
   if (piece >= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
