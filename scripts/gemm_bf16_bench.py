@@ -14,6 +14,8 @@ shapes = [("qkv img", 4096, 9216, 3072), ("o_proj img", 4096, 3072, 3072), ("fc1
           ("sd3 fc2", 8192, 1536, 6144)]
 if os.environ.get("SWEEP"):  # per-round fixed cost: the same 768 tiles (3 rounds of 256 CUs) at growing K; 204 tiles (one round)
     shapes = [(f"N12288 K{k}", 4096, 12288, k) for k in (512, 1024, 2048, 3072, 6144)] + [(f"N3072 K{k}", 4352, 3072, k) for k in (1024, 3072, 6144, 15360)]
+if os.environ.get("MF"):
+    ops.tune("gemm_mf", int(os.environ["MF"]))
 g = torch.Generator(device=dev).manual_seed(0)
 ncopy = int(os.environ.get("COLD_W", "1"))
 epi = {"bias": ops.DK_EPI_BIAS, "gelu": ops.DK_EPI_BIAS_GELU}[os.environ.get("EPI", "bias")]
@@ -36,4 +38,4 @@ for name, M, N, K in shapes:
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 24)
     out.append(f"{name} {M}x{N}x{K}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF")
-print(os.environ.get("DK_HIP_LIB", "default lib"), "EPI=" + os.environ.get("EPI", "bias"), "COLD_W=" + os.environ.get("COLD_W", "1"), " | ".join(out), flush=True)
+print(os.environ.get("DK_HIP_LIB", "default lib"), "MF=" + os.environ.get("MF", "auto"), "EPI=" + os.environ.get("EPI", "bias"), "COLD_W=" + os.environ.get("COLD_W", "1"), " | ".join(out), flush=True)
