@@ -39,6 +39,11 @@ for st in "$@"; do
       echo "prof exit $?" >> $OUT/prof_fp8.log; tail -n 3 $OUT/prof_fp8.log
       python scripts/rocpd_summary.py $(find $OUT/prof8 -name "*.db" | head -1) --by-grid > $OUT/kernel_stats_fp8.md 2>&1; head -n 14 $OUT/kernel_stats_fp8.md
       rm -rf $OUT/prof8 ;;
+    prof_sd3)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/profs -o sd3 -- python $OLDPWD/bench.py --workload sd3-medium-1024 --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/prof_sd3.log 2>&1)
+      echo "prof exit $?" >> $OUT/prof_sd3.log; tail -n 3 $OUT/prof_sd3.log
+      python scripts/rocpd_summary.py $(find $OUT/profs -name "*.db" | head -1) --by-grid > $OUT/kernel_stats_sd3.md 2>&1; head -n 14 $OUT/kernel_stats_sd3.md
+      rm -rf $OUT/profs ;;
     *) echo "unknown stage $st" ;;
   esac
 done
