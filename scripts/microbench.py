@@ -66,6 +66,9 @@ def main():
         x, sh, sc = rnd(1, 4352, 3072), rnd(1, 3072), rnd(1, 3072)
         ms = timeit(lambda: ops.ln_modulate(x, sh, sc))
         rows.append(("ln_modulate 4352x3072", ms, f"{2 * x.numel() * 2 / ms / 1e6:8.0f} GB/s ({2 * x.numel() * 2 / ms / 1e6 / 8000 * 100:.0f}% of 8 TB/s)"))
+        x3, sh3, sc3 = rnd(2, 4685, 1536), rnd(2, 1536), rnd(2, 1536)
+        ms = timeit(lambda: ops.ln_modulate(x3, sh3, sc3))
+        rows.append(("ln_modulate 2x4685x1536 (sd3)", ms, f"{2 * x3.numel() * 2 / ms / 1e6:8.0f} GB/s"))
         qkv = rnd(1, 4352, 9216)
         qw = rnd(128)
         tab = ops.rope_table(256, 64, 64, (16, 56, 56), 10000.0, dev)
