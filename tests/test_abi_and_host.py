@@ -152,3 +152,17 @@ def test_weight_pitch_rule_and_pitched_packing():
     assert torch.equal(p[b0][:, :r * h], w[b0]) and torch.all(p[b0][:, r * h:] == 0)
     assert torch.equal(p[s0 + ".linear2.weight"][:, h:(1 + r) * h], w[s0 + ".mlp.fc2.weight"])
     assert torch.all(p[s0 + ".linear2.weight"][:, (1 + r) * h:] == 0)
+
+
+def test_tune_keys_and_workspace_sizes():
+    """dk_tune_set knows every documented key (include/dk_hip.h) and rejects others with an error message; the
+    workspace-size queries answer without a GPU."""
+    from diffusionkit_amd import _lib
+    lib = _lib.load()
+    for key in (b"gemm", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"attn", b"attn_balance", b"attn_fuse_q"):
+        assert lib.dk_tune_set(key, -1 if key not in (b"gemm_fuse_k", b"attn_fuse_q") else 1) == 0, key
+    assert lib.dk_tune_set(b"gemm_sched", 0) == -1  # a knob of the removed kernel generations
+    assert b"unknown tuning key" in lib.dk_last_error()
+    assert lib.dk_gemm_workspace_bytes() == 256 * 256 * 256 * 4 + 4096
+    assert lib.dk_attention_workspace_bytes() % 1024 == 0 and lib.dk_attention_workspace_bytes() > 4096
+    assert lib.dk_attention_set_workspace(None, 0) == 0
