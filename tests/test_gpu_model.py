@@ -298,20 +298,21 @@ def test_flux_width_block_pair_full_sequence(dev):
     psnr_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], "flux width")
 
 
-@pytest.mark.parametrize("B,mf", [(1, -1), (2, 8), (2, 7)])
-def test_fused_key_norm_matches_separate_pass(dev, B, mf):
+@pytest.mark.parametrize("B,mf,side", [(1, -1, 128), (2, 8, 128), (2, 7, 128), (1, 8, 104), (2, 7, 104)])
+def test_fused_key_norm_matches_separate_pass(dev, B, mf, side):
     """QKNorm + RoPE of the keys inside the q / k / v projection's tail (dk_tune_set("gemm_fuse_k", 1), default) against the
     stand-alone pass over the projection's output (0): FLUX geometry, depth 1+1 -- double block (two streams, own weights and
     positions) and single block (column-split linear1); two images: rows of both sequences inside one launch, with 224-row tiles
-    straddling the sequence boundary.  Same values up to the summation order of a head's squares."""
+    straddling the sequence boundary; latent side 104: 2704 image tokens, the last tile of every stream ragged.  Same values up to
+    the summation order of a head's squares."""
     from dataclasses import replace
     from diffusionkit_amd import ops
     cfg = replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1)
     eng, _ = build(cfg, dev)
     text = randn(B, 256, cfg.token_level_text_embed_dim, seed=3)
     pooled = randn(B, cfg.pooled_text_embed_dim, seed=4)
-    lat = randn(B, 128, 128, 16, seed=5)
-    eng.prepare(B, (128, 128), 256, 2)
+    lat = randn(B, side, side, 16, seed=5)
+    eng.prepare(B, (side, side), 256, 2)
     eng.cache_modulation_params(pooled.to(dev), [1000.0, 752.0])
     tok = eng.patchify(lat.to(dev))
     outs = {}
