@@ -491,8 +491,12 @@ int g_dk_attn_balance = -1;
 
 // workspace of the balanced form: one slot per CU + 4 KiB of flags (zero before the first launch; the kernels leave them zero)
 size_t dk_attention_balance_workspace_bytes() {
-  int dev = 0, n_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+  static int n_cu = 0;  // (queried once: this runs on every attention launch of an engine call)
+  if (n_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cu = n;
+  }
   return (size_t)(n_cu + 1) * DK3_SLOT_BYTES + 4096;
 }
 
