@@ -304,7 +304,9 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
         # from the committed rocprofv3 --pmc passes over this same command (default workload, one image per step) and is attached
         # to that configuration only
-        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1 and not args.fp8:
+        if args.fp8:
+            pmc = os.path.join(ROOT, "profiles", "pmc_gemm_fp8_traffic.json")
+        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1:
             pj = json.load(open(pmc))
             traffic, traffic_src = pj.get("hbm_bytes_per_launch"), pj.get("source", "profiles/pmc_gemm_traffic.json")
 
