@@ -466,7 +466,6 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * HROWS;
   const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * HROWS : 0;
   const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
-  const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
   // read-back: a lane takes 8 consecutive columns (two 16-byte chunks) of one row, 4 lanes a 32-column row of the
   // image, 16 rows per step -- one 16-byte global store per lane and step (8-byte stores are issue-bound: half as
   // many instructions, guide T21).  Image swizzle chunk ^ ((row >> 1) & 7): conflict-free for the staging writes
