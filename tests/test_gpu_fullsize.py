@@ -33,6 +33,7 @@ TOL = {
     "vae_1024_raw": (None, 4.0e-2),     # ... decoder output before the clip
     "sd3_1024_final": (45.0, 2.5e-2),   # SD3 bench shape, depth 2, model output
     "flux_1024_final": (24.0, 2.5e-1),  # FLUX depth 4 + 8 at S = 4352 with N(0, 0.02) weights: the bf16-emulating oracle is at 26.8 dB / 0.17
+    "flux_1024_fp8_final": (22.0, 2.5e-1),  # ... with e4m3 weights / MX-fp8 activations (measured 26.2 dB / 0.187: 0.6 dB below the bf16 path)
     "flux_full_latent": (20.0, None),   # BASELINE configs[1] end to end (57 blocks x 4 steps); the reference's own image gate is 20 dB
 }
 
@@ -113,6 +114,16 @@ def test_flux_1024_depth_4_8_vs_oracle(dev):
     """FLUX.1-schnell geometry at S = 256 + 4096, 4 double + 8 single blocks"""
     f = load("flux_1024")
     check("flux_1024_final", torch.from_numpy(f["final_fp32"]), _forward(fx.FLUX_1024, dev), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
+
+
+def test_flux_1024_depth_4_8_fp8_weights_vs_oracle(dev):
+    """The same 4 + 8 blocks with e4m3 weights and MX-fp8 activations on the block Linears (BASELINE configs[3]'s arithmetic) against
+    the fp32 oracle with the ORIGINAL weights: the distance is the quantisation noise of the format plus the bf16 path's."""
+    from dataclasses import replace
+    f = load("flux_1024")
+    c = dict(fx.FLUX_1024)
+    c["cfg"] = replace(c["cfg"], weight_dtype="fp8_e4m3")
+    check("flux_1024_fp8_final", torch.from_numpy(f["final_fp32"]), _forward(c, dev), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
 
 
 def test_flux_schnell_1024_full_depth_pipeline(dev):
