@@ -34,7 +34,8 @@ TOL = {
     "sd3_1024_final": (45.0, 2.5e-2),   # SD3 bench shape, depth 2, model output
     "flux_1024_final": (24.0, 2.5e-1),  # FLUX depth 4 + 8 at S = 4352 with N(0, 0.02) weights: the bf16-emulating oracle is at 26.8 dB / 0.17
     "flux_1024_fp8_final": (22.0, 2.5e-1),  # ... with e4m3 weights / MX-fp8 activations (measured 26.2 dB / 0.187: 0.6 dB below the bf16 path)
-    "flux_full_latent": (20.0, None),   # BASELINE configs[1] end to end (57 blocks x 4 steps); the reference's own image gate is 20 dB
+    "flux_full_latent": (20.0, None),
+    "flux_full_fp8_latent": (25.0, None),  # the same image with e4m3 weights / MX-fp8 activations (measured 31.0 dB; bf16 path 32.0)   # BASELINE configs[1] end to end (57 blocks x 4 steps); the reference's own image gate is 20 dB
 }
 
 
@@ -137,3 +138,19 @@ def test_flux_schnell_1024_full_depth_pipeline(dev):
     lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
                                   seed=c["noise_seed"])
     check("flux_full_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
+
+
+def test_flux_schnell_1024_full_depth_pipeline_fp8_weights(dev):
+    """BASELINE configs[1]'s image with configs[3]'s arithmetic: FLUX.1-schnell, 19 + 38 blocks, 4 Euler steps, e4m3 weights and
+    MX-fp8 activations on every block Linear, against the fp32 oracle's latent (original weights)"""
+    from dataclasses import replace
+    from diffusionkit_amd.pipeline import FluxPipeline
+    f = load("flux_full")
+    c = fx.FLUX_FULL
+    cfg = replace(c["cfg"], weight_dtype="fp8_e4m3")
+    packed = {"mmdit": pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=c["seed_w"]), dev, consume=True)}
+    pipe = FluxPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed, mmdit_config=cfg)
+    text, pooled = fx.flux_full_inputs()
+    lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
+                                  seed=c["noise_seed"])
+    check("flux_full_fp8_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
