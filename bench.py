@@ -121,49 +121,42 @@ def cpu_baseline(image_flops, budget_s=30.0):
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on
-    127.0.0.1) and relay rank 0's JSON line."""
+    127.0.0.1), relay rank 0's JSON line, and -- if any rank fails -- the tail of that rank's stderr."""
     import socket
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     sys.stdout.write(out.decode())
     sys.stdout.flush()
+    for r, (rc, f) in enumerate(zip(rcs, errs)):
+        f.seek(0)
+        tail = f.read().decode(errors="replace")
+        if rc != 0:
+            sys.stderr.write(f"---- rank {r} exited with {rc}; stderr tail ----\n{tail[-4000:]}\n")
+        elif r == 0 and tail:
+            sys.stderr.write(tail[-2000:])
     sys.exit(max(abs(rc) for rc in rcs))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "flux-dev-1024", "tiny"])
-    ap.add_argument("--batch", type=int, default=1,
-                    help="images per rank and step, denoised in one batched step loop (FLUX workloads; default 1 = BASELINE configs[1]; "
-                         "8 on 8 GPUs = configs[4])")
-    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) weights + MX-fp8 activations on the block-scaled fp8 MFMA (BASELINE configs[3])")
-    ap.add_argument("--guidance-embed", action="store_true",
-                    help="FLUX.1-dev guidance embedding on (config FLUX_DEV); off = the reference's behaviour, which runs dev on the schnell preset")
-    ap.add_argument("--overlap-decode", action="store_true",
-                    help="decode image i on a side stream while image i+1 is denoised (DiffusionPipeline.decode_async); the default, and the "
-                         "headline, is the reference's order: denoise, then decode, image by image")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="dk_tune_set knob for A/B runs, e.g. --tune gemm_mf=8 (default kernels otherwise)")
-    args = ap.parse_args()
+WORKLOAD_NAMES = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-dev-1024": "FLUX.1-dev 1024x1024 50-step",
+                  "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "tiny": "tiny"}
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args.gpus)
 
+def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4):
+    """One bench leg: build the pipeline of `workload` on this rank, `warmup` untimed images, EXACTLY `steps` timed images
+    (each = the denoising steps + the VAE decode) bracketed by barrier + synchronize on both sides, max over ranks; then the
+    per-launch HIP-event replay for the roofline figures (rank 0).  Returns a dict of measurements (rank 0) or None."""
     from dataclasses import replace
 
     import numpy as np
@@ -175,33 +168,25 @@ def main():
     from diffusionkit_amd.pipeline import DiffusionPipeline, FluxPipeline
     from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
 
-    rank, local_rank, world = dk.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    lib = _lib.load()
-    for kv in args.tune:
-        k, v = kv.split("=")
-        _lib.check(lib.dk_tune_set(k.encode(), int(v)), "dk_tune_set")
-
-    if args.workload == "flux-schnell-1024":
+    rank, world, dev, lib = ctx["rank"], ctx["world"], ctx["dev"], ctx["lib"]
+    if workload == "flux-schnell-1024":
         cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 4, 0.0, 1.0, 256, 1
-    elif args.workload == "flux-dev-1024":
+    elif workload == "flux-dev-1024":
         # BASELINE configs[3] shape: 50 steps, 512 text tokens; like the reference (quirk Q7) FLUX.1-dev runs without its guidance
         # embedding unless --guidance-embed
-        cfg, vcfg, cls, mv = (FLUX_DEV if args.guidance_embed else FLUX_SCHNELL), VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-dev"
+        cfg, vcfg, cls, mv = (FLUX_DEV if guidance_embed else FLUX_SCHNELL), VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-dev"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 0.0, 1.0, 512, 1
-    elif args.workload == "sd3-medium-1024":
+    elif workload == "sd3-medium-1024":
         cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 5.0, 3.0, 589, 2
     else:
         cfg, vcfg, cls, mv = tiny_flux(), tiny_vae(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (16, 16), 4, 0.0, 1.0, 64, 1
-    if args.fp8:
-        assert cfg.is_flux and args.workload != "tiny", "--fp8 is offered for the FLUX workloads (head_dim 128, token counts multiples of 128)"
+    if fp8:
+        assert cfg.is_flux and workload != "tiny", "--fp8 is offered for the FLUX workloads (head_dim 128, token counts multiples of 128)"
         cfg = replace(cfg, weight_dtype="fp8_e4m3")
+    assert B >= 1 and (B == 1 or rows == 1), "--batch > 1 is offered for the FLUX workloads (one conditioning row per image)"
 
     # ---- weights: rank 0 creates them, one RCCL broadcast of the packed blob over xGMI ----
     t0 = time.perf_counter()
@@ -217,6 +202,7 @@ def main():
     packed = dk.broadcast_weights(packed, dev, src=0)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
+    blob_bytes = sum(v.numel() * v.element_size() for v in packed.values())
     weights = {"mmdit": {k[6:]: v for k, v in packed.items() if k.startswith("mmdit/")},
                "vae_decoder": {k[4:]: v for k, v in packed.items() if k.startswith("vae/")}}
     pipe = cls(w16=True, a16=True, shift=shift, model_version=mv, mmdit_config=cfg, vae_config=vcfg, device=dev,
@@ -227,11 +213,7 @@ def main():
     cond = torch.randn(rows, S_t, cfg.token_level_text_embed_dim, generator=g).to(dev, torch.bfloat16)
     pooled = torch.randn(rows, cfg.pooled_text_embed_dim, generator=g).to(dev, torch.bfloat16)
 
-    B = args.batch
-    assert B >= 1 and (B == 1 or rows == 1), "--batch > 1 is offered for the FLUX workloads (one conditioning row per image)"
-
     denoise_ms, vae_ms = [], []
-
     pending = []
 
     def one_image(seed):
@@ -240,7 +222,7 @@ def main():
         lat, _ = pipe.denoise_latents(cond, pooled, num_steps=num_steps, cfg_weight=cfg_weight, latent_size=latent,
                                       seed=seed if B == 1 else [seed * B + b for b in range(B)])
         e1.record()
-        if args.overlap_decode:
+        if overlap_decode:
             pending.append(pipe.decode_async(lat))  # waited for in barrier(): every image is decoded inside the timed region
             u8 = None
         else:
@@ -256,33 +238,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         one_image(1000 + i)
     barrier()
     t0 = time.perf_counter()
     evs = []
-    for i in range(args.steps):
+    for i in range(steps):
         u8, ev = one_image(rank * 100000 + i)
         evs.append(ev)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's own time (reported per rank; `elapsed` below is the contract's figure)
     barrier()
     elapsed = time.perf_counter() - t0
     for e0, e1, e2 in evs:
         denoise_ms.append(e0.elapsed_time(e1))
         vae_ms.append(e1.elapsed_time(e2))
+    per_rank = [steps * B / own]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine = torch.tensor([steps * B / own], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
 
     # ---- roofline of the dominant kernel (the block Linears' MFMA GEMM), HIP events on the launch stream ----
     S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
     step_flops = mmdit_step_flops(cfg, S_t, S_i, rows)  # per image
     image_flops = num_steps * step_flops + vae_flops(vcfg, *latent)
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if want_roofline and rank == 0:
         # the replay is bounded (at most 4 images: a 50-step image alone is ~10 000 launches); every launch of it is recorded
         # (the event pool grows on demand and dk_profile_read fails if a launch was dropped)
-        n_replay = min(args.steps, 4)
+        n_replay = min(steps, max_replay)
         lib.dk_profile_enable(1)
         t1 = time.perf_counter()
         for i in range(n_replay):
@@ -295,18 +284,16 @@ def main():
             _lib.check(lib.dk_profile_read(cls_id, C.byref(ms), C.byref(work), C.byref(n)), "dk_profile_read")
             stats[name] = (ms.value, work.value, n.value)
         lib.dk_profile_enable(0)
-        dom = "gemm_fp8" if args.fp8 else "gemm"
-        peak = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
+        dom = "gemm_fp8" if fp8 else "gemm"
+        peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
         ms, work, n = stats[dom]
         ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
         # from the committed rocprofv3 --pmc passes over this same command (default workload, one image per step) and is attached
         # to that configuration only
-        if args.fp8:
-            pmc = os.path.join(ROOT, "profiles", "pmc_gemm_fp8_traffic.json")
-        if os.path.exists(pmc) and args.workload == "flux-schnell-1024" and B == 1:
+        pmc = os.path.join(ROOT, "profiles", "pmc_gemm_fp8_traffic.json" if fp8 else "pmc_gemm_traffic.json")
+        if os.path.exists(pmc) and workload == "flux-schnell-1024" and B == 1:
             pj = json.load(open(pmc))
             traffic, traffic_src = pj.get("hbm_bytes_per_launch"), pj.get("source", "profiles/pmc_gemm_traffic.json")
 
@@ -317,7 +304,7 @@ def main():
 
         roofline = {
             "bound": "mfma",
-            "kernel": ("dk_gemm256f8_kernel (e4m3 x e4m3 block-scaled 16x16x128-MFMA GEMM)" if args.fp8 else
+            "kernel": ("dk_gemm256f8_kernel (e4m3 x e4m3 block-scaled 16x16x128-MFMA GEMM)" if fp8 else
                        "dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMM; small-M shapes: dk_gemm_bf16_kernel<0>)"),
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": traffic_src,
@@ -329,36 +316,118 @@ def main():
             "instrumented_ms_per_step": round(instr / n_replay * 1e3, 2),
             "method": "HIP events around every launch on the launch stream, replay of the timed region",
         }
-        if args.fp8:
+        if fp8:
             roofline["bf16_gemm"] = sub("gemm")
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
-        cpu = cpu_baseline(image_flops)
-
+    res = None
     if rank == 0:
-        value = world * args.steps * B / elapsed
-        ms_per_step = elapsed / args.steps * 1e3
-        names = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-dev-1024": "FLUX.1-dev 1024x1024 50-step",
-                 "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "tiny": "tiny"}
-        peak_whole = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
-        out = {
-            "metric": f"images/sec (whole node) {names[args.workload]}",
-            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8 e4m3 weights x MX-fp8 activations (fp32 accumulate), bf16 elsewhere" if args.fp8 else "bf16",
-            "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
-            "config": {"workload": f"{args.workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
-                                   f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8"
-                                   + (", guidance embedding on" if cfg.guidance_embed else "")
-                                   + (", decode of image i overlapped with the denoising of image i+1 (side stream)" if args.overlap_decode else ""),
-                       "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
+        peak_whole = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
+        res = {
+            "value": round(world * steps * B / elapsed, 4), "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "dtype": "fp8 e4m3 weights x MX-fp8 activations (fp32 accumulate), bf16 elsewhere" if fp8 else "bf16",
+            "workload": f"{workload}: latent {latent[0]}x{latent[1]}, {num_steps} Euler steps, cfg_weight {cfg_weight}, "
+                        f"text tokens {S_t}, batch {B} image{'s' if B > 1 else ''} per GPU per step, + VAE decode to uint8"
+                        + (", guidance embedding on" if cfg.guidance_embed else "")
+                        + (", decode of image i overlapped with the denoising of image i+1 (side stream)" if overlap_decode else ""),
             "denoise_ms_per_step": round(float(np.mean(denoise_ms)) / num_steps, 2),
             "vae_decode_ms": round(float(np.mean(vae_ms)), 2),
             "algorithmic_tflop_per_image": round(image_flops / 1e12, 2),
-            "mfma_roofline_frac_whole_path": round(image_flops * args.steps * B / elapsed / (peak_whole * 1e12), 4),
-            "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "mfma_roofline_frac_whole_path": round(image_flops * steps * B / elapsed / (peak_whole * 1e12), 4),
+            "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3), "weight_blob_gb": round(blob_bytes / 1e9, 2),
+            "per_rank_images_per_s": [round(v, 4) for v in per_rank],
+            "roofline": roofline, "image_flops": image_flops,
+        }
+    del pipe, weights, packed
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "flux-dev-1024", "tiny"])
+    ap.add_argument("--batch", default="1",
+                    help="images per rank and step, denoised in one batched step loop (FLUX workloads).  Default 1 = BASELINE configs[1] "
+                         "per GPU.  BASELINE configs[4] (FLUX.1-schnell, batch 64 sharded over 8 GPUs) is `--gpus 8 --batch 8`; "
+                         "`--batch auto` picks that per-GPU shape (8) whenever --gpus > 1 and 1 on a single GPU")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) weights + MX-fp8 activations on the block-scaled fp8 MFMA (BASELINE configs[3])")
+    ap.add_argument("--guidance-embed", action="store_true",
+                    help="FLUX.1-dev guidance embedding on (config FLUX_DEV); off = the reference's behaviour, which runs dev on the schnell preset")
+    ap.add_argument("--overlap-decode", action="store_true",
+                    help="decode image i on a side stream while image i+1 is denoised (DiffusionPipeline.decode_async); the default, and the "
+                         "headline, is the reference's order: denoise, then decode, image by image")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of BASELINE configs[2] (SD3-medium 1024x1024, 50 steps, CFG 5) and configs[3] (FLUX.1-dev, 50 steps, "
+                         "fp8 weights) that the default single-GPU headline run appends as `other_configs`")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="dk_tune_set knob for A/B runs, e.g. --tune gemm_mf=8 (default kernels otherwise)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+
+    import torch
+    import torch.distributed as dist
+    from diffusionkit_amd import _lib
+    from diffusionkit_amd import dist as dk
+
+    rank, local_rank, world = dk.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(lib.dk_tune_set(k.encode(), int(v)), "dk_tune_set")
+    B = (8 if world > 1 else 1) if args.batch == "auto" else int(args.batch)
+    ctx = {"rank": rank, "world": world, "dev": dev, "lib": lib}
+
+    head = run_workload(ctx, args.workload, args.fp8, B, args.steps, args.warmup, guidance_embed=args.guidance_embed,
+                        overlap_decode=args.overlap_decode, want_roofline=not args.no_roofline)
+
+    # ---- the other north-star configurations on the same driver-timed line (single-GPU headline runs only): short bounded legs,
+    # same code path and timing contract as the headline (warm-up, barrier + synchronize brackets, decode inside the region) ----
+    other = None
+    if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune:
+        other = {}
+        for key, (wl, fp8, n_img) in {"sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2),
+                                     "flux-dev-1024 fp8 (BASELINE configs[3])": ("flux-dev-1024", True, 2)}.items():
+            r = run_workload(ctx, wl, fp8, 1, n_img, 1, want_roofline=not args.no_roofline, max_replay=1)
+            rf = r["roofline"] or {}
+            other[key] = {"metric": f"images/sec {WORKLOAD_NAMES[wl]}", "value": r["value"], "unit": "images/s", "steps": n_img, "warmup": 1,
+                          "ms_per_step": r["ms_per_step"], "denoise_ms_per_step": r["denoise_ms_per_step"], "vae_decode_ms": r["vae_decode_ms"],
+                          "dtype": r["dtype"], "workload": r["workload"], "algorithmic_tflop_per_image": r["algorithmic_tflop_per_image"],
+                          "mfma_roofline_frac_whole_path": r["mfma_roofline_frac_whole_path"],
+                          "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "attention", "conv", "bf16_gemm") if k in rf}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
+        cpu = cpu_baseline(head["image_flops"])
+
+    if rank == 0:
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001  (version query only)
+            rccl = None
+        out = {
+            "metric": f"images/sec (whole node) {WORKLOAD_NAMES[args.workload]}",
+            "value": head["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": head["dtype"],
+            "data": "synthetic (seeded random weights and conditioning; reference numpy noise draw)",
+            "config": {"workload": head["workload"], "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
+            "denoise_ms_per_step": head["denoise_ms_per_step"], "vae_decode_ms": head["vae_decode_ms"],
+            "algorithmic_tflop_per_image": head["algorithmic_tflop_per_image"],
+            "mfma_roofline_frac_whole_path": head["mfma_roofline_frac_whole_path"],
+            "weight_init_s": head["weight_init_s"], "weight_bcast_s": head["weight_bcast_s"], "weight_blob_gb": head["weight_blob_gb"],
+            "world": world, "rccl_version": rccl, "collective_backend": "nccl (RCCL)" if world > 1 else None,
+            "per_rank_images_per_s": head["per_rank_images_per_s"],
+            "roofline": head["roofline"], "cpu_baseline": cpu, "other_configs": other,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

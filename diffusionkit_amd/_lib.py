@@ -129,6 +129,7 @@ SIGNATURES = {
     "dk_mmdit_cache_modulation_params": (_i32, [_vp, _vp, _fp, _i32, _vp]),
     "dk_mmdit_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "dk_mmdit_cache_context": (_i32, [_vp, _vp, _vp]),
+    "dk_mmdit_run_blocks": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dk_mmdit_debug_buffer": (_vp, [_vp, _i32]),
     "dk_vae_create": (_i32, [C.POINTER(dk_vae_config), C.POINTER(_vp)]),
     "dk_vae_destroy": (None, [_vp]),

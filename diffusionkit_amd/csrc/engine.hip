@@ -178,12 +178,16 @@ static Mx8Out mx8_out(void* out, void* scales, int ldo, long rows, int row0, int
 extern "C" int dk_quantize_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, void* out, int32_t ldo, void* out_scales, int64_t out_rows,
                                int32_t out_row0, int32_t out_col0, void* stream) {
   DK_REQUIRE(x && out && out_scales && M > 0, "bad argument");
+  DK_REQUIRE(out_row0 >= 0 && (int64_t)out_row0 + M <= out_rows, "rows [out_row0, out_row0 + M) must lie inside the [out_rows, ldo] output");
+  DK_REQUIRE(out_col0 >= 0 && ldo >= out_col0 + h, "columns [out_col0, out_col0 + h) must lie inside a row of ldo bytes");
   return dk_launch_quantize_mx8((const bf16_t*)x, ldx, M, 0, M, h, mx8_out(out, out_scales, ldo, (long)out_rows, out_row0, M, 0, out_col0), S_(stream));
 }
 extern "C" int dk_ln_modulate_mx8(const void* x, int32_t ldx, int32_t M, int32_t h, const void* shift, const void* scale, int32_t mod_stride,
                                   int32_t mod_seg_len, float eps, void* out, int32_t ldo, void* out_scales, int64_t out_rows,
                                   int32_t out_row0, void* stream) {
   DK_REQUIRE(x && out && out_scales && M > 0, "bad argument");
+  DK_REQUIRE(out_row0 >= 0 && (int64_t)out_row0 + M <= out_rows, "rows [out_row0, out_row0 + M) must lie inside the [out_rows, ldo] output");
+  DK_REQUIRE(ldo >= h, "a row of the output holds h bytes");
   return dk_launch_ln_modulate_mx8((const bf16_t*)x, ldx, M, h, (const bf16_t*)shift, (const bf16_t*)scale, mod_stride,
                                    mod_seg_len > 0 ? mod_seg_len : M, M, 0, eps, mx8_out(out, out_scales, ldo, (long)out_rows, out_row0, M, 0, 0),
                                    S_(stream));
@@ -620,7 +624,6 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
   DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
   DK_CHECK_HIP(hipMemsetAsync((char*)m->AWS + dk_attention_balance_workspace_bytes() - 4096, 0, 4096, st));
-  g_linear_ws = m->GWS;
   m->prepared = true;
   m->mod_ready = false;
   m->ctx_ready = false;
@@ -633,6 +636,7 @@ extern "C" int dk_mmdit_cache_modulation_params(dk_mmdit* m, const void* pooled,
   DK_REQUIRE(m && m->prepared, "dk_mmdit_prepare must be called first");
   DK_REQUIRE(n > 0 && n <= m->n_t, "more timesteps than the workspace was prepared for");
   hipStream_t st = S_(stream);
+  LinearWsScope ws_scope(m->GWS);
   const int h = m->h(), B = m->B, P = m->cfg.pooled_text_embed_dim, Fq = m->cfg.frequency_embed_dim;
   DK_CHECK_HIP(hipMemcpyAsync(m->tdev, timesteps_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
   DK_TRY(dk_launch_timestep_embedding(m->tdev, n, 1, Fq, (float)m->cfg.max_period, m->cfg.embed_dtype, m->temb, st));
@@ -689,6 +693,7 @@ static int post_sdpa_seq(dk_mmdit* m, const StreamW& w, int row_off, int S_s, co
 
 extern "C" int dk_mmdit_cache_context(dk_mmdit* m, const void* text, void* stream) {
   DK_REQUIRE(m && m->prepared && text, "prepare must precede cache_context");
+  LinearWsScope ws_scope(m->GWS);
   const dk_mmdit_config& c = m->cfg;
   const int M = m->B * m->S_t;
   DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, M, 0, m->ctx_w, m->ctx_b, m->CTXE, m->h(), M, 0, M, m->h(),
@@ -732,7 +737,8 @@ static void f8_gate_res(GemmF8Params& p, const bf16_t* gate, int gate_seg_len, i
 }
 static int f8_pair(const GemmF8Params& a, const GemmF8Params* b, hipStream_t st) { return dk_launch_gemm256f8(a, b, st); }
 
-static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st) {
+// blocks [first, first + count) of the global order (double blocks, then single blocks)
+static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int count, hipStream_t st) {
   const dk_mmdit_config& c = m->cfg;
   const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, r = c.mlp_ratio;
   const int mod_stride = m->mod_rows() * h;
@@ -746,6 +752,7 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
   // joint stream (b * S + s)
   const Mx8Out xn_img = mx8_out(m->XN8, m->SXN, h, BS, 0, Mi, 0, 0), xn_txt = mx8_out(m->XN8, m->SXN, h, BS, Mi, Mt, 0, 0);
   for (int i = 0; i < c.depth_multimodal; ++i) {
+    if (i < first || i >= first + count) continue;
     const bf16_t* mod_img = mod_step + (size_t)m->mod_offset(0, i) * h;
     const bf16_t* mod_txt = mod_step + (size_t)m->mod_offset(1, i) * h;
     const StreamW& wi = m->dimg[i];
@@ -821,6 +828,7 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
   const int M = B * S;
   const Mx8Out xn_all = mx8_out(m->XN8, m->SXN, h, BS, 0, M, 0, 0);
   for (int i = 0; i < c.depth_unified; ++i) {
+    if (c.depth_multimodal + i < first || c.depth_multimodal + i >= first + count) continue;
     const StreamW& w = m->single[i];
     const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
     DK_TRY(dk_launch_ln_modulate_mx8(m->X, h, M, h, mod, mod + h, mod_stride, S, M, 0, c.layer_norm_eps, xn_all, st));
@@ -851,41 +859,20 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, hipStream_t st)
   return 0;
 }
 
-extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index, void* tokens_out,
-                                void* stream) {
-  DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
-  DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
-  hipStream_t st = S_(stream);
-  g_linear_ws = m->GWS;
-  struct AttnWsScope {  // this call's attention launches hand off through this engine's region; the caller's setting comes back
-    void* prev = dk_get_attention_workspace();
-    ~AttnWsScope() { dk_set_attention_workspace(prev); }
-  } attn_ws_scope;
-  dk_set_attention_workspace(m->AWS);
+struct MmditCallScope {  // an engine call's GEMM splits and attention hand-offs go through THAT engine's regions; the caller's settings come back
+  LinearWsScope lin;
+  void* prev_attn;
+  explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS), prev_attn(dk_get_attention_workspace()) { dk_set_attention_workspace(m->AWS); }
+  ~MmditCallScope() { dk_set_attention_workspace(prev_attn); }
+};
+
+// The transformer blocks [first, first + count) of the global order (double blocks 0 .. depth_multimodal - 1, then single blocks)
+// on the joint residual stream m->X, bf16 Linears.
+static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int count, hipStream_t st) {
   const dk_mmdit_config& c = m->cfg;
-  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F(), r = c.mlp_ratio;
-  const int R = m->mod_rows();
-  const int mod_stride = R * h;  // per batch row
-  const bf16_t* mod_step = m->MOD + (size_t)step_index * B * R * h;
+  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, r = c.mlp_ratio;
+  const int mod_stride = m->mod_rows() * h;  // per batch row
   const float scale = 1.0f / sqrtf((float)m->D());
-
-  // context_embedder (mmdit.py:195): text rows of the joint stream -- recomputed from `text`, or copied from the
-  // step-invariant result of dk_mmdit_cache_context when `text` is null
-  if (text != nullptr) {
-    DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, B * S_t, 0, m->ctx_w, m->ctx_b, m->X, h, S_t, S, B * S_t, h,
-                       c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
-  } else {
-    DK_REQUIRE(m->ctx_ready, "forward without text needs dk_mmdit_cache_context first");
-    DK_CHECK_HIP(hipMemcpy2DAsync(m->X, (size_t)S * h * 2, m->CTXE, (size_t)S_t * h * 2, (size_t)S_t * h * 2, B, hipMemcpyDeviceToDevice, st));
-  }
-  // x_embedder (+ learned positional embedding) (mmdit.py:197-206): image rows
-  DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
-                     c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
-
-  if (m->fp8()) {
-    DK_TRY(mmdit_blocks_fp8(m, mod_step, st));
-    return mmdit_final_layer(m, mod_step, (bf16_t*)tokens_out, st);
-  }
   // MultiModalTransformerBlock x depth_multimodal (mmdit.py:568-675).  The two streams run the same
   // Linear shapes on different weights; their GEMMs are issued as pairs so that the 256 x 256 kernel can
   // place the text tiles in the same wave as the image tiles (dk_launch_gemm_pair).
@@ -898,6 +885,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   bf16_t* X_txt = m->X;
   const int Mi = B * S_i, Mt = B * S_t;
   for (int i = 0; i < c.depth_multimodal; ++i) {
+    if (i < first || i >= first + count) continue;
     const bf16_t* mod_img = mod_step + (size_t)m->mod_offset(0, i) * h;
     const bf16_t* mod_txt = mod_step + (size_t)m->mod_offset(1, i) * h;
     const StreamW& wi = m->dimg[i];
@@ -964,6 +952,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
 
   // UnifiedTransformerBlock x depth_unified (mmdit.py:693-751), parallel attention + MLP
   for (int i = 0; i < c.depth_unified; ++i) {
+    if (c.depth_multimodal + i < first || c.depth_multimodal + i >= first + count) continue;
     const StreamW& w = m->single[i];
     const bf16_t* mod = mod_step + (size_t)m->mod_offset(2, i) * h;
     const int M = B * S, ldcat = m->ldcat;
@@ -988,7 +977,52 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
                        m->X, h, M, 0, st, ldcat));
   }
 
+  return 0;
+}
+
+extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index, void* tokens_out,
+                                void* stream) {
+  DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede forward");
+  DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
+  hipStream_t st = S_(stream);
+  MmditCallScope scope(m);
+  const dk_mmdit_config& c = m->cfg;
+  const int h = m->h(), B = m->B, S = m->S, S_t = m->S_t, S_i = m->S_i, F = m->F();
+  const bf16_t* mod_step = m->MOD + (size_t)step_index * B * m->mod_rows() * h;
+
+  // context_embedder (mmdit.py:195): text rows of the joint stream -- recomputed from `text`, or copied from the
+  // step-invariant result of dk_mmdit_cache_context when `text` is null
+  if (text != nullptr) {
+    DK_TRY(linear_call((const bf16_t*)text, c.token_level_text_embed_dim, B * S_t, 0, m->ctx_w, m->ctx_b, m->X, h, S_t, S, B * S_t, h,
+                       c.token_level_text_embed_dim, DK_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, 0, st));
+  } else {
+    DK_REQUIRE(m->ctx_ready, "forward without text needs dk_mmdit_cache_context first");
+    DK_CHECK_HIP(hipMemcpy2DAsync(m->X, (size_t)S * h * 2, m->CTXE, (size_t)S_t * h * 2, (size_t)S_t * h * 2, B, hipMemcpyDeviceToDevice, st));
+  }
+  // x_embedder (+ learned positional embedding) (mmdit.py:197-206): image rows
+  DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
+                     c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
+  const int n_blocks = c.depth_multimodal + c.depth_unified;
+  DK_TRY(m->fp8() ? mmdit_blocks_fp8(m, mod_step, 0, n_blocks, st) : mmdit_blocks_bf16(m, mod_step, 0, n_blocks, st));
   return mmdit_final_layer(m, mod_step, (bf16_t*)tokens_out, st);
+}
+
+// Teacher-forced block range (include/dk_hip.h): x_in -> m->X, blocks [first, first + count), m->X -> x_out
+extern "C" int dk_mmdit_run_blocks(dk_mmdit* m, const void* x_in, void* x_out, int32_t step_index, int32_t first_block, int32_t n_blocks,
+                                   void* stream) {
+  DK_REQUIRE(m && m->prepared && m->mod_ready, "prepare + cache_modulation_params must precede run_blocks");
+  DK_REQUIRE(x_in && x_out, "null argument");
+  DK_REQUIRE(step_index >= 0 && step_index < m->n_t, "step index out of range");
+  const int total = m->cfg.depth_multimodal + m->cfg.depth_unified;
+  DK_REQUIRE(first_block >= 0 && n_blocks >= 1 && first_block + n_blocks <= total, "block range outside the model");
+  hipStream_t st = S_(stream);
+  MmditCallScope scope(m);
+  const size_t bytes = (size_t)m->B * m->S * m->h() * 2;
+  const bf16_t* mod_step = m->MOD + (size_t)step_index * m->B * m->mod_rows() * m->h();
+  DK_CHECK_HIP(hipMemcpyAsync(m->X, x_in, bytes, hipMemcpyDeviceToDevice, st));
+  DK_TRY(m->fp8() ? mmdit_blocks_fp8(m, mod_step, first_block, n_blocks, st) : mmdit_blocks_bf16(m, mod_step, first_block, n_blocks, st));
+  DK_CHECK_HIP(hipMemcpyAsync(x_out, m->X, bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
 }
 
 extern "C" const void* dk_mmdit_debug_buffer(const dk_mmdit* m, int32_t which) {

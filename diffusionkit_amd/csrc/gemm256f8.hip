@@ -135,8 +135,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   // E8M0 scales of this wave's 128 A rows for one K-tile: 8 bytes per lane (byte mf = row mf * 16 + l15, block q), one
   // coalesced 512-byte read per wave (layout: dk_mx_scale_index).  The wave's rows must be one aligned 128-row block of the
   // physical buffer (checked by the launcher: segments and offsets are multiples of 128 rows).
+  // (clamped to the last row block of M: the second wave row of a tile whose rows end at m0 + 128 owns no rows -- its results are
+  //  masked -- and must not read scale bytes past the caller's side array)
   const int mrow0 = m0 + wm * 128;
-  const unsigned a_blk = (unsigned)(((mrow0 / p.a_seg_len) * p.a_seg_stride + (mrow0 % p.a_seg_len) + p.a_row0) >> 7);
+  const int mrow_sc = min(mrow0, (p.M - 1) & ~127);
+  const unsigned a_blk = (unsigned)(((mrow_sc / p.a_seg_len) * p.a_seg_stride + (mrow_sc % p.a_seg_len) + p.a_row0) >> 7);
   const unsigned char* sa_ptr = p.SA + ((size_t)a_blk * 64 + lane) * 8;
   const size_t sa_step = (size_t)p.sa_nblk * 512;  // bytes between K-tiles
   u32x2 sa_cur, sa_nxt;

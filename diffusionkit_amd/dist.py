@@ -45,11 +45,13 @@ def shard_seeds(seeds: Sequence[int], rank: int, world: int) -> List[int]:
 
 
 def broadcast_weights(packed: Optional[Dict[str, torch.Tensor]], device, src: int = 0,
-                      chunk_elems: int = _CHUNK_ELEMS) -> Dict[str, torch.Tensor]:
+                      chunk_elems: int = _CHUNK_ELEMS, force: bool = False) -> Dict[str, torch.Tensor]:
     """Root packs its engine tensors into one byte blob; every rank receives blob + index and
     rebuilds zero-copy views.  One collective per ``chunk_elems`` bytes (4 GiB by default: the bf16 FLUX blob of
-    23.8 GB goes out in 6 calls)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    23.8 GB goes out in 6 calls).  A single-rank run returns ``packed`` untouched unless ``force`` (an initialised process
+    group of world size 1 then goes through the same pack / broadcast / unpack calls: how the single-GPU test box exercises
+    the RCCL path, tests/test_gpu_dist.py)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         assert packed is not None
         return packed
     rank = dist.get_rank()

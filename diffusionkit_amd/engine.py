@@ -174,6 +174,23 @@ class MMDiTEngine:
                                              tokens_out.data_ptr(), _stream()), "dk_mmdit_forward")
         return tokens_out
 
+    def run_blocks(self, x: Tensor, step_index: int, first_block: int, n_blocks: int = 1) -> Tensor:
+        """MultiModalTransformerBlock / UnifiedTransformerBlock.__call__ (mmdit.py:568-675, 693-751) on a caller-supplied joint
+        residual stream ``x`` (bf16 [batch, S_t + S_i, h], text rows first): blocks ``first_block .. first_block + n_blocks - 1`` of
+        the global order (double blocks, then single blocks) with the modulation cached for ``step_index``."""
+        _require_cuda(x, "x", torch.bfloat16)
+        b, hl, wl, s_t, _ = self._shape
+        p = self.config.patch_size
+        want = (b, s_t + (hl // p) * (wl // p), self.config.hidden_size)
+        if tuple(x.shape) != want:
+            raise _lib.DkHipError(f"x shape {tuple(x.shape)} != {want}")
+        if not (0 <= step_index < self._n_cached):
+            raise KeyError(f"no cached modulation parameters for step {step_index}")
+        out = torch.empty_like(x)
+        _lib.check(self.lib.dk_mmdit_run_blocks(self._h, x.data_ptr(), out.data_ptr(), step_index, first_block, n_blocks, _stream()),
+                   "dk_mmdit_run_blocks")
+        return out
+
     def patchify(self, latent: Tensor, dup: int = 1) -> Tensor:
         """LatentImageAdapter reshape (mmdit.py:292-300): f32 NHWC -> bf16 tokens."""
         _require_cuda(latent, "latent", torch.float32)

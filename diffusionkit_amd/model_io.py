@@ -69,8 +69,14 @@ def flux_checkpoint_to_reference(sd: StateDict, cfg: MMDiTConfig) -> StateDict:
         if stem in _FLUX_TOP:
             out[f"{_FLUX_TOP[stem]}.{leaf}"] = take(k)
             continue
-        if stem.startswith("guidance_in."):  # FLUX.1-dev guidance embedding: unused by the reference (Q7)
-            used.add(k)
+        if stem.startswith("guidance_in."):
+            # FLUX.1-dev guidance embedding (MLPEmbedder in_layer / out_layer -> mlp.layers.0 / .2, as the reference's
+            # flux_state_dict_adjustments renames every in_layer / out_layer, model_io.py:292-298).  The reference then runs dev on
+            # the schnell preset (quirk Q7) and never reads them: kept only when the configuration asks for the embedding
+            if cfg.guidance_embed and stem in ("guidance_in.in_layer", "guidance_in.out_layer"):
+                out[f"guidance_in.mlp.layers.{0 if stem.endswith('in_layer') else 2}.{leaf}"] = take(k)
+            else:
+                used.add(k)
             continue
         m = re.fullmatch(r"double_blocks\.(\d+)\.(img|txt)_attn\.norm\.(query|key)_norm\.scale", k)
         if m:

@@ -100,7 +100,11 @@ class DiffusionPipeline:
     ):
         _lib.load()  # fail loudly before anything else if the HIP extension is missing
         # The MI355X build computes in bf16 end to end (BASELINE.json configs); w16/a16 are
-        # accepted for signature compatibility.
+        # accepted for signature compatibility.  The reference's defaults (w16 = a16 = False) mean fp32 weights / activations
+        # there (mlx/__init__.py:76-79): say at run time that this build does not offer that mode instead of silently changing it
+        if not (w16 and a16):
+            logger.warning(f"w16={w16}, a16={a16}: fp32 weights / activations are not offered by the MI355X build; "
+                           "computing with bf16 weights and bf16 activations (fp32 accumulation, fp32 latent state)")
         self.float16_dtype = torch.bfloat16
         self.dtype = torch.bfloat16
         self.activation_dtype = torch.bfloat16
@@ -406,12 +410,17 @@ class DiffusionPipeline:
         stream has been made to wait for the decode.  Same kernels, same results as ``decoder.decode``."""
         if not hasattr(self, "_decode_stream"):
             self._decode_stream = torch.cuda.Stream(device=self.device)
+            # the side stream owns a decoder engine of its own (same weight tensors, its own workspace and split flags): an inline
+            # ``decoder.decode`` on the caller's stream may run while a PendingDecode is in flight without sharing scratch with it;
+            # consecutive async decodes are ordered by the side stream itself
+            from .engine import VAEDecoderEngine
+            self._async_decoder = VAEDecoderEngine(self.decoder.config, self.decoder.weights)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._decode_stream):
             self._decode_stream.wait_event(ready)
             latents.record_stream(self._decode_stream)
-            img, u8, _ = self.decoder.decode(latents)
+            img, u8, _ = self._async_decoder.decode(latents)
             done = torch.cuda.Event()
             done.record(self._decode_stream)
         return PendingDecode(img, u8, done, self.device)
@@ -424,7 +433,12 @@ class PendingDecode:
         self._img, self._u8, self._done, self._device = img, u8, done, device
 
     def result(self):
-        torch.cuda.current_stream(self._device).wait_event(self._done)
+        cur = torch.cuda.current_stream(self._device)
+        cur.wait_event(self._done)
+        # the tensors were allocated under the side stream: tell the caching allocator that the caller's stream reads them, so
+        # that their blocks are not handed to the next side-stream decode while those readers are still queued
+        self._img.record_stream(cur)
+        self._u8.record_stream(cur)
         return self._img, self._u8
 
 

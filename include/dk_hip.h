@@ -288,6 +288,14 @@ int dk_mmdit_cache_context(dk_mmdit* m, const void* text, void* stream);
  * tokens_out: bf16 [batch, S_i, p*p*C] (FinalLayer output). */
 int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* text, int32_t step_index,
                      void* tokens_out, void* stream);
+/* MultiModalTransformerBlock.__call__ / UnifiedTransformerBlock.__call__ (mmdit.py:568-675, 693-751) on a caller-supplied
+ * residual stream: copies x_in (bf16 [batch, S, h], the engine's joint layout: text rows first, then image rows, per batch row)
+ * into the engine's stream, runs blocks [first_block, first_block + n_blocks) of the global order (double blocks
+ * 0 .. depth_multimodal - 1, then the single blocks) with the modulation parameters cached for `step_index`, and copies the
+ * stream to x_out.  The operator-level boundary of one reference block: the teacher-forced parity tests drive single blocks
+ * of the full-size model through it (tests/test_gpu_fullsize.py). */
+int dk_mmdit_run_blocks(dk_mmdit* m, const void* x_in, void* x_out, int32_t step_index, int32_t first_block,
+                        int32_t n_blocks, void* stream);
 /* read-only view of an internal buffer for parity taps: 0 = joint residual stream [B,S,h],
  * 1 = modulation table [n*B, rows*h] */
 const void* dk_mmdit_debug_buffer(const dk_mmdit* m, int32_t which);

@@ -163,7 +163,7 @@ class OracleMMDiT:
     """
 
     def __init__(self, cfg, weights: Dict[str, Tensor], prec: Optional[Prec] = None, gelu: str = "erf", act_quant=None,
-                 guidance: Optional[float] = None):
+                 guidance: Optional[float] = None, embed_prec: Optional[Prec] = None):
         self.cfg = cfg
         self.w = weights
         self.P = prec or Prec()
@@ -175,7 +175,14 @@ class OracleMMDiT:
         self.gelu = {"erf": gelu_erf, "tanh": gelu_tanh}[gelu]  # "erf" = the MLX path (quirk Q3)
         # timestep embedding is evaluated in config.dtype independently of the activation
         # dtype (quirk Q2); the exact oracle keeps it exact.
-        self.P_embed = Prec(embed_dtype(cfg)) if self.P.act is not None else Prec()
+        # ``embed_prec`` overrides that: the reference evaluates frequencies / arguments / cos / sin in ``config.dtype`` whatever
+        # the activation dtype is (mmdit.py:379-389: bf16 for FLUX, fp16 for SD3, also with a16 = False), so
+        # ``OracleMMDiT(cfg, w, Prec(), embed_prec=Prec(embed_dtype(cfg)))`` is the function the reference computes with fp32
+        # activations.  It matters: t = 752 times a bf16-rounded frequency moves the phase of the fast sinusoids by radians, and
+        # the whole modulation table with it -- a fp32 oracle WITHOUT the quirk sits 11 % (rel-L2 of a FLUX block's image
+        # stream) away from any implementation WITH it, bf16 rounding noise is 0.7 % (round 3: what held the FLUX full-size
+        # fixtures of round 2 at 27-32 dB).
+        self.P_embed = embed_prec if embed_prec is not None else (Prec(embed_dtype(cfg)) if self.P.act is not None else Prec())
         self._mod: Dict[str, Dict[float, Tensor]] = {}
         self._rope = None
         self._rope_key = None

@@ -144,6 +144,28 @@ def test_flux_checkpoint_round_trip(tmp_path):
     assert got["x_embedder.proj.weight"].shape == (cfg.hidden_size, 1, 1, cfg.patch_dim)
 
 
+def test_flux_dev_checkpoint_keeps_guidance_embedding(tmp_path):
+    """guidance_embed = True (FLUX_DEV preset): guidance_in.{in,out}_layer -> guidance_in.mlp.layers.{0,2}; the packer finds them
+    (the loader used to drop every guidance_in.* key, so a real FLUX.1-dev checkpoint could not be packed)."""
+    from dataclasses import replace
+    from safetensors.torch import save_file
+    from diffusionkit_amd.weights import mmdit_weight_shapes
+    cfg = replace(tiny_flux(), guidance_embed=True)
+    w = synth_mmdit_weights(cfg, seed=9)
+    ck = to_bfl_flux(w, cfg)
+    for ref, bfl in (("guidance_in.mlp.layers.0", "guidance_in.in_layer"), ("guidance_in.mlp.layers.2", "guidance_in.out_layer")):
+        for leaf in ("weight", "bias"):
+            ck[f"{bfl}.{leaf}"] = w[f"{ref}.{leaf}"].contiguous()
+    path = os.path.join(tmp_path, "flux1-dev-tiny.safetensors")
+    save_file(ck, path)
+    got = mio.load_mmdit_checkpoint(path, cfg)
+    same(got, w)
+    assert set(got) == set(mmdit_weight_shapes(cfg))
+    # the same file under the schnell preset (what the reference selects for dev, quirk Q7): the four tensors are ignored
+    got_s = mio.load_mmdit_checkpoint(path, tiny_flux())
+    assert not any(k.startswith("guidance_in.") for k in got_s)
+
+
 def test_sd3_checkpoint_round_trip(tmp_path):
     from safetensors.torch import save_file
     cfg = tiny_sd3()
