@@ -43,6 +43,17 @@ class dk_conv_desc(C.Structure):
     ]
 
 
+class dk_conv_gn_desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
+        ("gn_scale_shift", C.c_void_p), ("gn_silu", C.c_int32),
+        ("x2", C.c_void_p), ("bias2", C.c_void_p), ("stats_partial", C.c_void_p),
+        ("image_f32", C.c_void_p), ("image_u8", C.c_void_p), ("raw_bf16", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("O", C.c_int32), ("C2", C.c_int32),
+        ("ldw", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32), ("upsample", C.c_int32), ("stats_groups", C.c_int32),
+    ]
+
+
 class dk_mmdit_config(C.Structure):
     _fields_ = [
         ("num_heads", C.c_int32), ("depth_multimodal", C.c_int32), ("depth_unified", C.c_int32),
@@ -95,6 +106,8 @@ SIGNATURES = {
     "dk_attention_workspace_bytes": (C.c_size_t, []),
     "dk_attention_set_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dk_conv3x3_bf16": (_i32, [C.POINTER(dk_conv_desc), _vp]),
+    "dk_conv3x3_gn_bf16": (_i32, [C.POINTER(dk_conv_gn_desc), _vp]),
+    "dk_groupnorm_table_bf16": (_i32, [_vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, C.c_float, _vp, _i32, _vp, _vp]),
     "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dk_attention_bias_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i32, _vp]),
     "dk_embedding_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),

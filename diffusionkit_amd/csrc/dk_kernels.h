@@ -204,7 +204,34 @@ int dk_launch_euler_step(float* x, const bf16_t* model_out, int ld_out, bf16_t* 
                          int Hl, int Wl, int C, int p, int reshape_order, float sigma, float sigma_next,
                          float cfg_weight, hipStream_t stream);
 
+// ---- 3x3 conv with LDS halo staging and the GroupNorm-apply + SiLU prologue (conv_halo.hip) ----------------------------------
+struct ConvHaloParams {
+  const bf16_t* x;        // stored input NHWC [B, H >> ups, W >> ups, C] (RAW values when gn_ss is given)
+  const bf16_t* w;        // [O, ldw] K-major: column tap * C + c (tap = ky * 3 + kx), then (x2) 9 * C + c2
+  const bf16_t* bias;     // [O]
+  const bf16_t* bias2;    // bias of the shortcut extension, or null
+  const bf16_t* res;      // residual NHWC [B, H, W, ldr], or null
+  bf16_t* y;              // NHWC [B, H, W, ldy]
+  const float* gn_ss;     // [B][2][C] fp32 (scale | shift) of the GroupNorm applied to x on load, or null (x is used as it is)
+  int gn_silu;            // SiLU behind that GroupNorm
+  const bf16_t* x2;       // 1x1 shortcut input NHWC [B, H, W, C2] (raw), or null
+  int C2;
+  float* stats_out;       // [B][tiles per image][G_out][2] (sum, sum of squares) of the stored output, or null
+  int G_out;
+  float* img;             // image tail (O <= 4): clip(y / 2 + 0.5) f32 [npix, 3]
+  unsigned char* u8;      // ... (x 255) truncated to uint8 [npix, 3]
+  bf16_t* raw;            // ... y itself, bf16 [npix, 4]
+  int out_channels;
+  int B, H, W, C, O, ups, ldw, ldy, ldr;
+};
+bool dk_conv_halo_eligible(const ConvHaloParams& p, bool img);
+int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream);
+
 // ---- VAE ops -------------------------------------------------------------------------------
+// the second pass of the GroupNorm statistics alone: per (batch, group) the partials [B][nchunk][G][2] -> mean / rstd, and
+// (gamma given) the per-channel table scale_shift [B][2][C]: scale = rstd * gamma, shift = beta - mean * scale
+int dk_launch_groupnorm_finalize(const float* partial, int nchunk, int B, int G, double count, float eps, float* mean_rstd,
+                                 const bf16_t* gamma, const bf16_t* beta, int C, float* scale_shift, hipStream_t stream);
 int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk,
                               float* mean_rstd, float eps, hipStream_t stream);
 int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,

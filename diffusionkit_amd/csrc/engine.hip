@@ -25,6 +25,10 @@ int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the que
 // multiply) are stored with 64 elements of padding: a 24-30 KB row stride makes the K-tile DMA of 256 rows camp on a few
 // memory channels (linear2 of FLUX: 369 -> 345 us with the padded pitch, profiles/r01_gemm_lab_pitch.log).
 int g_dk_pitch_min_k = 8192;
+// dk_tune_set("conv_halo", v): the VAE's norm -> silu -> conv stages on the halo-staged kernel with the GroupNorm applied on load
+// (conv_halo.hip): -1 (default) where the output has fewer than 256 channels (the HBM-bound high-resolution stage and conv_out; the
+// 256 / 512-channel stages stay on the 256 x 256 implicit-GEMM kernel behind a GroupNorm-apply pass), 0 never, 1 wherever the shape allows
+int g_dk_conv_halo = -1;
 extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
@@ -36,6 +40,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
+  if (strcmp(key, "conv_halo") == 0) { g_dk_conv_halo = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }
@@ -244,6 +249,40 @@ extern "C" int dk_groupnorm_bf16(const void* x, void* y, int32_t B, int64_t HW, 
   if (rc) return rc;
   return dk_launch_groupnorm_apply((const bf16_t*)x, (bf16_t*)y, B, (long)HW, C, G, mean_rstd, (const bf16_t*)gamma,
                                    (const bf16_t*)beta, fuse_silu, S_(stream));
+}
+
+// scratch layout shared by dk_groupnorm_bf16 / dk_groupnorm_table_bf16: [partials: B * n * 2G][mean_rstd: B * G * 2], n = the
+// larger of 1024 and the caller's n_partial
+extern "C" int dk_groupnorm_table_bf16(const void* x, int32_t B, int64_t HW, int32_t C, int32_t G, const void* gamma, const void* beta,
+                                       float eps, float* scratch, int32_t n_partial, float* scale_shift, void* stream) {
+  DK_REQUIRE(gamma && beta && scratch && scale_shift && B > 0 && G > 0 && C % G == 0, "groupnorm table arguments");
+  DK_REQUIRE(x != nullptr || n_partial > 0, "either x or the number of partials a conv launch left in scratch");
+  const int nchunk = x ? gn_nchunk((long)HW, C) : n_partial;
+  float* mean_rstd = scratch + (size_t)B * (nchunk > 1024 ? nchunk : 1024) * 2 * G;
+  if (x) {
+    hipStream_t st = S_(stream);
+    const int rc = dk_launch_groupnorm_stats((const bf16_t*)x, B, (long)HW, C, G, scratch, nchunk, mean_rstd, eps, st);
+    if (rc) return rc;
+  }
+  return dk_launch_groupnorm_finalize(scratch, nchunk, B, G, (double)HW * (double)(C / G), eps, mean_rstd, (const bf16_t*)gamma,
+                                      (const bf16_t*)beta, C, scale_shift, S_(stream));
+}
+
+static ConvHaloParams conv_halo_params(const dk_conv_gn_desc* d) {
+  ConvHaloParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w; p.bias = (const bf16_t*)d->bias; p.bias2 = (const bf16_t*)d->bias2;
+  p.res = (const bf16_t*)d->res; p.y = (bf16_t*)d->y; p.gn_ss = d->gn_scale_shift; p.gn_silu = d->gn_silu;
+  p.x2 = (const bf16_t*)d->x2; p.C2 = d->C2; p.stats_out = d->stats_partial; p.G_out = d->stats_groups;
+  p.img = d->image_f32; p.u8 = d->image_u8; p.raw = (bf16_t*)d->raw_bf16; p.out_channels = d->O <= 4 ? d->O : 0;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.C = d->C; p.O = d->O; p.ups = d->upsample; p.ldw = d->ldw; p.ldy = d->ldy; p.ldr = d->ldr;
+  return p;
+}
+extern "C" int dk_conv3x3_gn_bf16(const dk_conv_gn_desc* d, void* stream) {
+  DK_REQUIRE(d && d->x && d->w && d->bias, "null argument");
+  const bool img = d->image_f32 || d->image_u8 || d->raw_bf16;
+  DK_REQUIRE(img || d->y, "no output");
+  return dk_launch_conv_halo(conv_halo_params(d), S_(stream));
 }
 
 extern "C" int dk_softmax_rows_bf16(void* x, int32_t rows, int32_t cols, int32_t ld, void* stream) {
@@ -1039,6 +1078,7 @@ struct dk_vae {
   // workspace views
   bf16_t *bufA, *bufB, *T1, *Y, *SC, *LAT, *ZERO, *Qb, *Kb, *Vb, *Vt, *SCORES;
   float* gn;
+  float *ss0, *ss1;  // GroupNorm (scale | shift) tables [B][2][C] of the fused norm -> silu -> conv stages
   void* GWS = nullptr;  // GEMM split workspace of this engine's launches (fp32 slabs + flags)
 };
 
@@ -1096,7 +1136,17 @@ static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
   v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
-  v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  {
+    // statistics scratch: up to 1024 chunk partials per batch row from the stand-alone pass, or one per 16 x 16 output tile of the
+    // largest stage from the fused convs, + mean / rstd
+    const size_t tiles = ((size_t)h << (cf.n_blocks - 1)) / 16 * (((size_t)w << (cf.n_blocks - 1)) / 16);
+    const size_t npart = tiles > 1024 ? tiles : 1024;
+    v->gn = (float*)c.take(((size_t)B * npart * 2 * cf.resnet_groups + (size_t)B * cf.resnet_groups * 2) * 4);
+    int cmax = 0;
+    for (int j = 0; j < cf.n_blocks; ++j) cmax = cf.block_out_channels[j] > cmax ? cf.block_out_channels[j] : cmax;
+    v->ss0 = (float*)c.take((size_t)B * 2 * cmax * 4);
+    v->ss1 = (float*)c.take((size_t)B * 2 * cmax * 4);
+  }
   v->GWS = c.take(dk_gemm_split_workspace_bytes());
   return c.off;
 }
@@ -1131,8 +1181,57 @@ struct VaeRun {
     d.epilogue = res ? DK_EPI_RES : DK_EPI_BIAS;
     return conv3x3_launch(&d, v->GWS, st);
   }
+  // ---- fused norm -> silu -> conv stages (conv_halo.hip) ----
+  int n_part = 0;  // > 0: v->gn holds the output-statistics partials [B][n_part][G][2] of the tensor the last fused conv wrote
+  bool halo_stage(int H, int Wd, int Cin, int Cout) const {
+    if (g_dk_conv_halo == 0 || H % 16 != 0 || Wd % 16 != 0 || Cin % 64 != 0 || Cout % 128 != 0) return false;
+    if ((size_t)H * Wd * (Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return false;
+    return g_dk_conv_halo > 0 || Cout < 256;
+  }
+  // the (scale | shift) table of GroupNorm `name` over tensor x: from the partials the producing conv left, or a statistics pass
+  int gn_table(const bf16_t* x, long HW, int C, const std::string& name, float* ss) {
+    const bf16_t *g = W(name + ".weight"), *b = W(name + ".bias");
+    if (rc) return rc;
+    const int np = n_part;
+    n_part = 0;
+    return dk_groupnorm_table_bf16(np > 0 ? nullptr : x, B, HW, C, v->cfg.resnet_groups, g, b, v->cfg.group_norm_eps, v->gn, np, ss, st);
+  }
+  // ResnetBlock2D (vae.py:60-101) in two launches + two statistics finalisations: x stays raw, both GroupNorm + SiLU are applied
+  // on the way into the convs' LDS halo tiles, conv1 / conv2 leave the statistics of their outputs behind (stats_next: somebody
+  // normalises `out` next), the 1x1 shortcut rides in conv2's reduction
+  int resnet_fused(const bf16_t* x, bf16_t* out, int H, int Wd, int Cin, int Cout, const std::string& p, bool stats_next) {
+    const long HW = (long)H * Wd;
+    const int tiles = (H / 16) * (Wd / 16), G = v->cfg.resnet_groups;
+    DK_TRY(gn_table(x, HW, Cin, p + ".norm1", v->ss0));
+    ConvHaloParams c;
+    memset(&c, 0, sizeof(c));
+    c.x = x; c.w = W(p + ".conv1.weight"); c.bias = W(p + ".conv1.bias"); c.y = v->Y; c.gn_ss = v->ss0; c.gn_silu = 1;
+    c.stats_out = v->gn; c.G_out = G;
+    c.B = B; c.H = H; c.W = Wd; c.C = Cin; c.O = Cout; c.ldw = 9 * Cin; c.ldy = Cout;
+    if (rc) return rc;
+    DK_TRY(dk_launch_conv_halo(c, st));
+    n_part = tiles;
+    DK_TRY(gn_table(v->Y, HW, Cout, p + ".norm2", v->ss1));
+    memset(&c, 0, sizeof(c));
+    c.x = v->Y; c.bias = W(p + ".conv2.bias"); c.y = out; c.gn_ss = v->ss1; c.gn_silu = 1;
+    c.B = B; c.H = H; c.W = Wd; c.C = Cout; c.O = Cout; c.ldy = Cout; c.ldr = Cout;
+    if (has(p + ".conv_shortcut.weight")) {
+      c.w = W(p + ".conv2_sc.weight");  // [conv2 | conv_shortcut] along the reduction (weights.pack_vae)
+      c.ldw = 9 * Cout + Cin; c.x2 = x; c.C2 = Cin; c.bias2 = W(p + ".conv_shortcut.bias");
+    } else {
+      DK_REQUIRE(Cin == Cout, "resnet without shortcut must keep the channel count");
+      c.w = W(p + ".conv2.weight"); c.ldw = 9 * Cout; c.res = x;
+    }
+    if (stats_next) { c.stats_out = v->gn; c.G_out = G; }
+    if (rc) return rc;
+    DK_TRY(dk_launch_conv_halo(c, st));
+    n_part = stats_next ? tiles : 0;
+    return 0;
+  }
   // ResnetBlock2D (vae.py:60-101): x [B,H,W,Cin] -> out [B,H,W,Cout]
-  int resnet(const bf16_t* x, bf16_t* out, int H, int Wd, int Cin, int Cout, const std::string& p) {
+  int resnet(const bf16_t* x, bf16_t* out, int H, int Wd, int Cin, int Cout, const std::string& p, bool stats_next = false) {
+    if (halo_stage(H, Wd, Cin, Cout) && (Cin == Cout || has(p + ".conv2_sc.weight"))) return resnet_fused(x, out, H, Wd, Cin, Cout, p, stats_next);
+    n_part = 0;
     const long HW = (long)H * Wd;
     DK_TRY(gn(x, v->T1, HW, Cin, p + ".norm1", 1));
     DK_TRY(conv(v->T1, v->Y, H, Wd, Cin, Cout, p + ".conv1", 0, nullptr, Cout));
@@ -1210,13 +1309,28 @@ extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int3
     const int Cout = cf.block_out_channels[j];
     for (int r = 0; r < cf.layers_per_block; ++r) {
       const std::string p = "up_blocks." + std::to_string(j) + ".resnets." + std::to_string(r);
-      DK_TRY(R.resnet(cur, nxt, H, W, r == 0 ? C : Cout, Cout, p)); std::swap(cur, nxt);
+      // (somebody normalises the output next: the following resnet, or conv_norm_out behind the last block)
+      const bool gn_next = r + 1 < cf.layers_per_block || j == 0;
+      DK_TRY(R.resnet(cur, nxt, H, W, r == 0 ? C : Cout, Cout, p, gn_next)); std::swap(cur, nxt);
     }
     C = Cout;
     if (j > 0) {
       H *= 2; W *= 2;
+      R.n_part = 0;
       DK_TRY(R.conv(cur, nxt, H, W, C, C, "up_blocks." + std::to_string(j) + ".upsample", 1, nullptr, C)); std::swap(cur, nxt);
     }
+  }
+  if (g_dk_conv_halo != 0 && H % 16 == 0 && W % 16 == 0 && C % 64 == 0 && cf.out_channels <= 4 && (size_t)H * W * C * 2 < (1ull << 31)) {
+    // conv_norm_out -> silu -> conv_out -> clip / uint8 (vae.py:381,384,397-399; __init__.py:581-584,525-526) in one launch
+    DK_TRY(R.gn_table(cur, (long)H * W, C, "conv_norm_out", v->ss0));
+    ConvHaloParams c;
+    memset(&c, 0, sizeof(c));
+    c.x = cur; c.w = R.W("conv_out.weight"); c.bias = R.W("conv_out.bias"); c.gn_ss = v->ss0; c.gn_silu = 1;
+    c.img = image_f32; c.u8 = image_u8; c.raw = raw_bf16 ? (bf16_t*)raw_bf16 : v->Y; c.out_channels = cf.out_channels;
+    c.B = batch; c.H = H; c.W = W; c.C = C; c.O = cf.out_channels; c.ldw = 9 * C;
+    if (R.rc) return R.rc;
+    DK_TRY(dk_launch_conv_halo(c, st));
+    return R.rc;
   }
   DK_TRY(R.gn(cur, v->T1, (long)H * W, C, "conv_norm_out", 1));
   bf16_t* raw = raw_bf16 ? (bf16_t*)raw_bf16 : v->Y;
@@ -1260,7 +1374,15 @@ static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
   v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
-  v->gn = (float*)c.take(dk_groupnorm_scratch_floats(B, cf.resnet_groups) * 4);
+  {
+    const size_t tiles = ((size_t)H / 16) * ((size_t)W / 16);
+    const size_t npart = tiles > 1024 ? tiles : 1024;
+    v->gn = (float*)c.take(((size_t)B * npart * 2 * cf.resnet_groups + (size_t)B * cf.resnet_groups * 2) * 4);
+    int cmax = 0;
+    for (int j = 0; j < cf.n_blocks; ++j) cmax = cf.block_out_channels[j] > cmax ? cf.block_out_channels[j] : cmax;
+    v->ss0 = (float*)c.take((size_t)B * 2 * cmax * 4);
+    v->ss1 = (float*)c.take((size_t)B * 2 * cmax * 4);
+  }
   v->GWS = c.take(dk_gemm_split_workspace_bytes());
   return c.off;
 }

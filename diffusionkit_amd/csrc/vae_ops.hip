@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
 }
 // one wave per (batch, group): lanes stride over the chunk partials, fixed-order shuffle tree (double)
 __global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
-                                                            float* __restrict__ mean_rstd) {
+                                                            float* __restrict__ mean_rstd, const bf16_t* __restrict__ gamma,
+                                                            const bf16_t* __restrict__ beta, int C, float* __restrict__ scale_shift) {
   const int b = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
   for (int c = lane; c < nchunk; c += 64) {
@@ -84,6 +85,28 @@ __global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restr
     mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
     mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
+  if (scale_shift != nullptr) {
+    // the per-channel pair dk_gn_apply_kernel builds in LDS (same fp32 expressions), for consumers that apply the norm on load
+    const double mean = __shfl(s, 0, 64) / count;
+    double var = __shfl(q, 0, 64) / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+    const int cpg = C / G;
+    for (int c = lane; c < cpg; c += 64) {
+      const int ch = g * cpg + c;
+      const float sc = rf * bf2f(gamma[ch]);
+      scale_shift[(size_t)b * 2 * C + ch] = sc;
+      scale_shift[(size_t)b * 2 * C + C + ch] = bf2f(beta[ch]) - mf * sc;
+    }
+  }
+}
+int dk_launch_groupnorm_finalize(const float* partial, int nchunk, int B, int G, double count, float eps, float* mean_rstd,
+                                 const bf16_t* gamma, const bf16_t* beta, int C, float* scale_shift, hipStream_t stream) {
+  DK_REQUIRE(G >= 1 && nchunk >= 1 && (scale_shift == nullptr || (gamma && beta && C % G == 0)), "groupnorm finalize arguments");
+  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B * G), dim3(64), 0, stream, partial, nchunk, G, count, eps, mean_rstd, gamma, beta, C,
+                     scale_shift);
+  DK_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, float* mean_rstd,
                               float eps, hipStream_t stream) {
@@ -92,10 +115,7 @@ int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, flo
   DK_REQUIRE(nchunk >= 1, "nchunk");
   hipLaunchKernelGGL(dk_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, HW, C, G, partial, nchunk);
   DK_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B * G), dim3(64), 0, stream, partial, nchunk, G,
-                     (double)HW * (double)(C / G), eps, mean_rstd);
-  DK_CHECK_HIP(hipGetLastError());
-  return 0;
+  return dk_launch_groupnorm_finalize(partial, nchunk, B, G, (double)HW * (double)(C / G), eps, mean_rstd, nullptr, nullptr, C, nullptr, stream);
 }
 
 // y = [silu]( bf16( (x - mean) * rstd * gamma + beta ) ), evaluated as x * scale[c] + shift[c] with the per-channel

@@ -108,6 +108,64 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False
     return y[..., :O]
 
 
+def groupnorm_table(x: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float, partials: Optional[Tensor] = None,
+                    shape=None) -> Tensor:
+    """(scale | shift) table [B, 2, C] fp32 of nn.GroupNorm over NHWC ``x`` -- or over the tensor whose output-statistics
+    ``partials`` [B, n, G, 2] a ``conv3x3_gn`` launch produced (then ``shape`` = (B, H*W, C))."""
+    lib = _lib.load()
+    if x is not None:
+        _require_cuda(x, "x", BF)
+        B, HW, Cc = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+        n_part = 0
+        scratch = torch.empty(lib.dk_groupnorm_scratch_floats(B, groups), dtype=torch.float32, device=x.device)
+    else:
+        B, HW, Cc = shape
+        n_part = partials.shape[1]
+        scratch = torch.empty(B * max(1024, n_part) * 2 * groups + B * groups * 2, dtype=torch.float32, device=partials.device)
+        scratch[:partials.numel()] = partials.reshape(-1)
+    ss = torch.empty(B, 2, Cc, dtype=torch.float32, device=gamma.device)
+    _lib.check(lib.dk_groupnorm_table_bf16(_ptr(x), B, HW, Cc, groups, gamma.data_ptr(), beta.data_ptr(), eps, scratch.data_ptr(),
+                                           n_part, ss.data_ptr(), _stream()), "dk_groupnorm_table_bf16")
+    return ss
+
+
+def conv3x3_gn(x: Tensor, w: Tensor, bias: Tensor, gn_table: Optional[Tensor] = None, silu: bool = True, res: Optional[Tensor] = None,
+               x2: Optional[Tensor] = None, bias2: Optional[Tensor] = None, stats_groups: int = 0, upsample: bool = False,
+               image: bool = False):
+    """norm -> silu -> conv3x3 as one launch (csrc/conv_halo.hip): ``x`` raw NHWC, ``gn_table`` from ``groupnorm_table``;
+    ``w`` [O, 9 C (+ C2)] K-major.  Returns y, or (y, partials) with ``stats_groups``, or (image_f32, image_u8, raw) with ``image``."""
+    lib = _lib.load()
+    _require_cuda(x, "x", BF)
+    _require_cuda(w, "w", BF)
+    B, Hs, Ws, Cc = x.shape
+    H, W_ = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    O = w.shape[0]
+    w2 = w.reshape(O, -1)
+    d = _lib.dk_conv_gn_desc()
+    d.x, d.w, d.bias, d.res = x.data_ptr(), w2.data_ptr(), bias.data_ptr(), _ptr(res)
+    d.gn_scale_shift, d.gn_silu = _ptr(gn_table), int(silu)
+    d.x2, d.bias2 = _ptr(x2), _ptr(bias2)
+    d.B, d.H, d.W, d.C, d.O, d.C2 = B, H, W_, Cc, O, (x2.shape[-1] if x2 is not None else 0)
+    d.ldw, d.upsample = w2.shape[1], int(upsample)
+    out = None
+    if image:
+        img = torch.empty(B, H, W_, 3, dtype=torch.float32, device=x.device)
+        u8 = torch.empty(B, H, W_, 3, dtype=torch.uint8, device=x.device)
+        raw = torch.empty(B, H, W_, 4, dtype=BF, device=x.device)
+        d.image_f32, d.image_u8, d.raw_bf16 = img.data_ptr(), u8.data_ptr(), raw.data_ptr()
+        out = (img, u8, raw)
+    else:
+        y = torch.empty(B, H, W_, O, dtype=BF, device=x.device)
+        d.y, d.ldy, d.ldr = y.data_ptr(), O, (res.shape[-1] if res is not None else 0)
+        out = y
+        if stats_groups:
+            part = torch.empty(B, (H // 16) * (W_ // 16), stats_groups, 2, dtype=torch.float32, device=x.device)
+            d.stats_partial, d.stats_groups = part.data_ptr(), stats_groups
+            out = (y, part)
+    _lib.check(lib.dk_conv3x3_gn_bf16(C.byref(d), _stream()), "dk_conv3x3_gn_bf16")
+    return out
+
+
 _attn_ws = {}
 
 

@@ -343,6 +343,12 @@ def pack_vae(cfg, w: Dict[str, Tensor], device) -> Dict[str, Tensor]:
         if t.dim() == 4:
             t = t.reshape(t.shape[0], -1)
         out[k] = t.to(torch.bfloat16).contiguous()
+    # channel-changing resnets (vae.py:86-89,98-99): [conv2 | conv_shortcut] along the reduction, for the fused stage that runs the
+    # 1x1 shortcut as extra K-tiles of conv2 (csrc/conv_halo.hip); the separate tensors stay for the unfused path
+    for k in list(out):
+        if k.endswith(".conv_shortcut.weight"):
+            stem = k[:-len(".conv_shortcut.weight")]
+            out[stem + ".conv2_sc.weight"] = torch.cat([out[stem + ".conv2.weight"], out[k]], dim=1).contiguous()
     return out
 
 

@@ -97,6 +97,39 @@ typedef struct dk_conv_desc {
 /* nn.Conv2d 3x3 / stride 1 / pad 1 call sites: vae.py:73,79,134,349,384 */
 int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream);
 
+/* The norm -> silu -> conv sequence of ResnetBlock2D (vae.py:72-73,78-79,91-100) and of the decoder's output head
+ * (conv_norm_out -> silu -> conv_out, vae.py:381,384,397-399) as ONE operator for the high-resolution stage: a 3x3 / stride 1 /
+ * pad 1 convolution whose workgroups stage an 18 x 18 halo of the RAW input in LDS per 16 x 16 output tile, applying the
+ * GroupNorm (as the per-channel fp32 pair from dk_groupnorm_table_bf16) and the SiLU on the way in -- the normalised tensor is
+ * never written.  Optionally: + residual (the block's "+ x", vae.py:100); the 1x1 conv_shortcut of a channel-changing block
+ * (vae.py:86-89,98-99) as extra reduction columns over x2 (w = [conv weight | shortcut weight], ldw = 9 C + C2 or more);
+ * (sum, sum of squares) partials of the output per channel group for the GroupNorm that reads it next (dk_groupnorm_table_bf16
+ * with x == NULL); and, for O <= 4 (conv_out), the clip / uint8 tail of decode_latents_to_image (__init__.py:581-584,525-526).
+ * H, W multiples of 16; C (and C2) multiples of 64; O a multiple of 128, or <= 4 with the image tail. */
+typedef struct dk_conv_gn_desc {
+  const void* x;       /* NHWC bf16 [B, H(/2), W(/2), C]                                          */
+  const void* w;       /* bf16 [O, ldw]: column (ky * 3 + kx) * C + c, then 9 C + c2              */
+  const void* bias;    /* [O]                                                                      */
+  void* y;             /* NHWC bf16 [B, H, W, ldy] (NULL with the image tail)                      */
+  const void* res;     /* NHWC bf16 [B, H, W, ldr] or NULL                                         */
+  const float* gn_scale_shift; /* [B, 2, C] fp32 from dk_groupnorm_table_bf16, or NULL: x as it is */
+  int32_t gn_silu;
+  const void* x2;      /* NHWC bf16 [B, H, W, C2] or NULL                                          */
+  const void* bias2;   /* [O] or NULL                                                              */
+  float* stats_partial;/* [B, (H/16)*(W/16), stats_groups, 2] fp32 or NULL                         */
+  float* image_f32;    /* image tail: [B, H, W, 3] in [0, 1]                                       */
+  uint8_t* image_u8;   /* ... [B, H, W, 3]                                                         */
+  void* raw_bf16;      /* ... conv output, bf16 [B, H, W, 4]                                       */
+  int32_t B, H, W, C, O, C2, ldw, ldy, ldr, upsample, stats_groups;
+} dk_conv_gn_desc;
+int dk_conv3x3_gn_bf16(const dk_conv_gn_desc* d, void* stream);
+/* nn.GroupNorm statistics (vae.py:34,72,78,381) as the table dk_conv3x3_gn_bf16 applies: scale = rstd * gamma, shift =
+ * beta - mean * scale, fp32 [B, 2, C].  x != NULL: statistics of x (NHWC bf16 [B, HW, C]); x == NULL: from `n_partial` partials
+ * per batch row that a dk_conv3x3_gn_bf16 launch left in scratch (layout [B, n_partial, G, 2]).  scratch:
+ * dk_groupnorm_scratch_floats(B, G) floats, or B * n_partial * G * 2 + B * G * 2 if that is more. */
+int dk_groupnorm_table_bf16(const void* x, int32_t B, int64_t HW, int32_t C, int32_t G, const void* gamma, const void* beta,
+                            float eps, float* scratch, int32_t n_partial, float* scale_shift, void* stream);
+
 /* mx.fast.scaled_dot_product_attention call sites mmdit.py:562,643,687,736.
  * q/k/v: row (b*S + s) at ptr + (b*S + s)*ld + head*D; out likewise with ldo.  D in {64,128}. */
 int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,

@@ -494,6 +494,76 @@ def test_groupnorm(dev, C, G, HW, silu):
     assert rel_l2(ref, y.float()) < 3e-3
 
 
+@pytest.mark.parametrize("B,H,W,C,O,res,sc,gn", [(1, 16, 16, 64, 128, False, 0, True),     # one tile: every border is padding
+                                                 (2, 32, 48, 128, 128, True, 0, True),     # 12 tiles, two 64-channel chunks, residual
+                                                 (1, 48, 32, 256, 128, False, 256, True),  # resnet with shortcut: 4 + 4 chunks
+                                                 (1, 32, 32, 64, 256, True, 0, False),     # plain conv (no table), two N-tiles
+                                                 (1, 64, 64, 128, 128, False, 128, True)])
+def test_conv3x3_gn_halo(dev, B, H, W, C, O, res, sc, gn):
+    """norm -> silu -> conv (+ residual / + 1x1 shortcut as extra reduction columns) in one launch (conv_halo.hip): against the
+    oracle's GroupNorm + SiLU + conv, against the unfused device path (dk_groupnorm_bf16 then dk_conv3x3_bf16: same arithmetic in
+    front of the MFMAs, other summation order), and the output statistics against a statistics pass over the stored output."""
+    from diffusionkit_amd import ops
+    G, eps = 32, 1e-5
+    x = bf16r(randn(B, H, W, C, seed=80, scale=1.5) + 0.3)
+    gamma, beta = bf16r(1 + randn(C, seed=81, scale=0.1)), randn(C, seed=82, scale=0.1)
+    w = randn(O, 3, 3, C, seed=83, scale=0.05)
+    b = randn(O, seed=84, scale=0.1)
+    r = randn(B, H, W, O, seed=85) if res else None
+    x2 = randn(B, H, W, sc, seed=86) if sc else None
+    ws = randn(O, sc, seed=87, scale=0.05) if sc else None
+    bs = randn(O, seed=88, scale=0.1) if sc else None
+    P = Prec(BF)
+    act = ov.silu(ov.group_norm_nhwc(x, gamma, beta, G, eps, P), P) if gn else x
+    ref = ov.conv2d_nhwc(act, w, b, Prec())
+    if res:
+        ref = ref + r
+    if sc:
+        ref = ref + (x2 @ ws.t() + bs)
+    xd = g(x, dev)
+    tab = ops.groupnorm_table(xd, g(gamma, dev), g(beta, dev), G, eps) if gn else None
+    wk = w.reshape(O, -1)
+    if sc:
+        wk = torch.cat([wk, ws], dim=1)
+    y, part = ops.conv3x3_gn(xd, g(wk, dev), g(b, dev), gn_table=tab, silu=True, res=g(r, dev) if res else None,
+                             x2=g(x2, dev) if sc else None, bias2=g(bs, dev) if sc else None, stats_groups=G)
+    assert y.shape == ref.shape
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+    # the unfused device path
+    actd = ops.groupnorm(xd, g(gamma, dev), g(beta, dev), G, eps, True) if gn else xd
+    if sc:
+        scd = ops.linear(g(x2, dev).reshape(-1, sc), g(ws, dev), g(bs, dev)).reshape(B, H, W, O)
+        y0 = ops.conv3x3(actd, g(w, dev), g(b, dev), res=scd)
+    else:
+        y0 = ops.conv3x3(actd, g(w, dev), g(b, dev), res=g(r, dev) if res else None)
+    assert max_abs(y0.float(), y.float()) <= 0.02 * float(ref.abs().max()) + 1e-2
+    # output statistics: the table built from the conv's partials == the table of a statistics pass over y
+    g2, b2 = bf16r(1 + randn(O, seed=89, scale=0.1)), randn(O, seed=90, scale=0.1)
+    t_part = ops.groupnorm_table(None, g(g2, dev), g(b2, dev), G, eps, partials=part, shape=(B, H * W, O))
+    t_pass = ops.groupnorm_table(y.contiguous(), g(g2, dev), g(b2, dev), G, eps)
+    assert rel_l2(t_pass.cpu(), t_part.cpu()) < 1e-5
+
+
+def test_conv_out_image_tail_halo(dev):
+    """conv_norm_out -> silu -> conv_out -> clip / uint8 (vae.py:381,384,397-399; __init__.py:581-584,525-526) in one launch"""
+    from diffusionkit_amd import ops
+    B, H, W, C, G, eps = 2, 32, 48, 128, 32, 1e-5
+    x = bf16r(randn(B, H, W, C, seed=91, scale=1.5) + 0.3)
+    gamma, beta = bf16r(1 + randn(C, seed=92, scale=0.1)), randn(C, seed=93, scale=0.1)
+    w = randn(3, 3, 3, C, seed=94, scale=0.05)
+    b = randn(3, seed=95, scale=0.1)
+    P = Prec(BF)
+    act = ov.silu(ov.group_norm_nhwc(x, gamma, beta, G, eps, P), P)
+    ref = bf16r(ov.conv2d_nhwc(act, w, b, Prec()))
+    xd = g(x, dev)
+    tab = ops.groupnorm_table(xd, g(gamma, dev), g(beta, dev), G, eps)
+    img, u8, raw = ops.conv3x3_gn(xd, g(w, dev).reshape(3, -1), g(b, dev), gn_table=tab, image=True)
+    assert rel_l2(ref, raw[..., :3].float()) < TOL_SINGLE_OP
+    want = torch.clip(raw[..., :3].float() / 2 + 0.5, 0, 1)
+    assert torch.equal(img, want) and torch.equal(u8, (want * 255).to(torch.uint8))
+    assert torch.all(raw[..., 3].float() == 0)
+
+
 def test_softmax_and_transpose(dev):
     from diffusionkit_amd import ops
     x = randn(64, 256, seed=70, scale=3.0)
