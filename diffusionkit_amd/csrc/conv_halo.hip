@@ -17,9 +17,12 @@
 // owns MF pixel rows (16 pixels = one MFMA fragment each) x NF 16-column fragments; v_mfma_f32_16x16x32_bf16 with the weight
 // fragment as the A operand (lane holds pixel l15, columns 4q .. 4q+3: row-major stores), fp32 accumulation in chunk-major order.
 //   LDS: two halo slots (324 rows x 160 B: 128 B of channels + 32 B pad, conflict-free ds_read_b128 for 16 consecutive rows)
-//        + two weight slots (NT rows x 128 B, XOR-swizzled 16-byte chunks as in gemm256v3.hip).
-//   Pipeline: weights of K-tile s+3 -> registers, K-tile s+1 registers -> LDS, while K-tile s multiplies; the halo of chunk c+1
-//   is loaded at the first tap of chunk c and transformed + stored during its later taps; one barrier per K-tile.
+//        + three weight slots (NT rows x 128 B, XOR-swizzled 16-byte chunks as in gemm256v3.hip).
+//   Pipeline: weights of K-tile s+4 -> registers, K-tile s+2 registers -> LDS, while K-tile s multiplies; the halo of chunk c+1
+//   is loaded at the first tap of chunk c and transformed + stored during its later taps; one barrier per K-tile.  The fragment
+//   reads run one half K-tile ahead of the MFMAs ACROSS that barrier: K-tile s+1's weights have been in LDS since the barrier
+//   before, its halo window since the chunk began, so the first fragments of s+1 are fetched while the second half of s multiplies
+//   (first version, one set of reads per K-tile behind the barrier: 760-915 TFLOP/s; profiles/r03_vae_kernel_stats_halo_v1.md).
 // Optional K extension (x2): the 1x1 conv_shortcut of a channel-changing resnet (vae.py:86-89,98-99) as extra K-tiles over the
 // raw block input (centre tap only, no transform) -- the shortcut never exists as a tensor.
 // Optional statistics of the OUTPUT (stats_out): per workgroup the (sum, sum of squares) of the stored bf16 values per output
@@ -28,6 +31,17 @@
 #include "dk_kernels.h"
 
 typedef __attribute__((address_space(3))) char lds_c;
+
+#ifndef CH_SGB
+#define CH_SGB 1  // sched_group_barrier pipeline inside a K-tile: 1 = one LDS read / memory instruction behind every MFMA (0: the compiler's own
+                  // order -- MFMAs in runs of 8-16 and the reads in front of them, both waves of a SIMD in the same phase: the MFMA time and
+                  // everything else then add up instead of overlapping, profiles/r03_conv_halo_ablations.md)
+#endif
+#ifndef CH_ABL
+#define CH_ABL 0  // lab only (scripts/build_halo_abl.sh), bit mask of what the K loop leaves out: 1 the MFMAs, 2 the fragment reads, 4 the
+                  // barriers, 8 the GroupNorm / SiLU transform, 16 the weight stream (loads + LDS stores), 32 the halo stream of the next
+                  // chunk (loads + LDS stores), 64 the output stores of the tail.  Results are wrong; the timings say what each part costs.
+#endif
 
 #define CH_ROWS 324          // 18 x 18 halo pixels
 #define CH_ROWB 160          // bytes per halo row in LDS
@@ -62,7 +76,10 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
 
   // ---- halo items of this thread: (halo row, 16-byte channel chunk c8 = tid & 7) ----
   const int c8 = tid & 7;
-  unsigned voff[CH_ITEMS], voff2[CH_ITEMS], lds_w[CH_ITEMS];
+  // (item i = halo row (tid >> 3) + 64 i: the LDS address is one lane-constant + i * 64 rows; the global offset is rebuilt per load
+  //  from the source pixel index -- 6 registers instead of 18 for the three address sets)
+  unsigned hpix[CH_ITEMS];  // source pixel of the item: (y >> ups) * Ws + (x >> ups) in the stored tensor (== y * W + x for the shortcut input)
+  const unsigned lds_w0 = (unsigned)((tid >> 3) * CH_ROWB + c8 * 16);
   unsigned okmask = 0u, inmask = 0u;
 #pragma unroll
   for (int i = 0; i < CH_ITEMS; ++i) {
@@ -72,9 +89,7 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
     const int y = ty * 16 - 1 + hy, x = tx * 16 - 1 + hx;
     const bool in = id < CH_ROWS * 8;
     const bool ok = in && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    voff[i] = ok ? ((unsigned)((y >> p.ups) * Ws + (x >> p.ups)) * (unsigned)p.C + c8 * 8u) * 2u : 0x80000000u;
-    voff2[i] = ok ? ((unsigned)(y * p.W + x) * (unsigned)p.C2 + c8 * 8u) * 2u : 0x80000000u;
-    lds_w[i] = (unsigned)(hrow * CH_ROWB + c8 * 16);
+    hpix[i] = ok ? (unsigned)((y >> p.ups) * Ws + (x >> p.ups)) : 0u;
     okmask |= (ok ? 1u : 0u) << i;
     inmask |= (in ? 1u : 0u) << i;
   }
@@ -124,17 +139,17 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
 //  next LDS read -- measured in the .s: vmcnt(0) at the head of every K-tile)
 #define CH_LOAD_W(REG, S)                                                                                           \
   do {                                                                                                              \
-    if (w_thread) { /* (NT = 128: a compile-time true) */                                                           \
+    if (w_thread && !(CH_ABL & 16)) { /* (NT = 128: a compile-time true) */                                         \
       const int sc_ = (S) < nkt ? (S) : nkt - 1;                                                                    \
       const int col_ = uint_(kt_col(sc_));                                                                          \
       _Pragma("unroll") for (int j = 0; j < W_ITEMS; ++j) REG[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wsrc[j], col_, 0); \
     }                                                                                                               \
   } while (0)
-#define CH_STORE_W(REG, S)                                                                                          \
+#define CH_STORE_W(REG, SLOT)                                                                                       \
   do {                                                                                                              \
-    if (w_thread) {                                                                                                 \
+    if (w_thread && !((CH_ABL & 16) && in_loop)) {                                                                  \
       _Pragma("unroll") for (int j = 0; j < W_ITEMS; ++j)                                                           \
-          *(__attribute__((address_space(3))) u32x4*)(lds + wdst[j] + ((S) & 1) * W_SLOT) = REG[j];                 \
+          *(__attribute__((address_space(3))) u32x4*)(lds + wdst[j] + (SLOT) * W_SLOT) = REG[j];                    \
     }                                                                                                               \
   } while (0)
   // halo of chunk c -> registers (raw bf16); chunks >= n_main come from the shortcut input.  (One code path, descriptor rebuilt from
@@ -146,41 +161,41 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
     const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(uptr(m_ ? (const void*)xb : (const void*)x2b), 0,     \
                                                                         uint_(m_ ? nrec_x : nrec_x2), 0x00020000);            \
     const int so_ = uint_((m_ ? c_ : c_ - n_main) * 128);                                                                     \
+    const unsigned cb_ = (unsigned)uint_((m_ ? p.C : p.C2) * 2); /* bytes per pixel of the source tensor */                   \
     _Pragma("unroll") for (int i = 0; i < CH_ITEMS; ++i)                                                                      \
-        REG[i] = __builtin_amdgcn_raw_buffer_load_b128(r_, (int)(m_ ? voff[i] : voff2[i]), so_, 0);                            \
+        REG[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                                        \
+            r_, (int)(((okmask >> i) & 1u) ? hpix[i] * cb_ + c8 * 16u : 0x80000000u /* padding: out of range -> zeros */), so_, 0); \
     const float* g_ = gsrc + (m_ ? c_ : 0) * 64 + c8 * 8;                                                                     \
     gt[0] = *(const f32x4*)g_, gt[1] = *(const f32x4*)(g_ + 4);                                                               \
     gt[2] = *(const f32x4*)(g_ + gsh_off), gt[3] = *(const f32x4*)(g_ + gsh_off + 4);                                         \
   } while (0)
   u32x4 hreg[CH_ITEMS];
-  // registers (hreg) -> (GroupNorm-apply + SiLU) -> LDS slot c & 1; items i0 .. i1-1
-  auto store_halo = [&](int c, int i0, int i1) {
-    const bool xform = gss != nullptr && c < n_main;
+  // registers (hreg) -> (GroupNorm-apply + SiLU) -> LDS halo slot `slot`; items i0 .. i1-1 of chunk c.  STRAIGHT-LINE code (masks and
+  // selects instead of branches, a dummy LDS zone behind the weight slots for the 480 threads without a sixth item): inside a K-tile
+  // it has to sit in the same scheduling region as the MFMAs it is to overlap with.
+  const unsigned dummy_w = (unsigned)(W_OFF + 3 * W_SLOT + tid * 16);
+  auto store_halo = [&](int slot, int c, int i0, int i1) {
+    const bool xform = gss != nullptr && c < n_main && !((CH_ABL & 8) && c > 0);
+    const unsigned xm = xform ? 0xFFFFFFFFu : 0u, sm = p.gn_silu ? 0xFFFFFFFFu : 0u;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) sc[e] = gt[0][e], sc[4 + e] = gt[1][e], sh[e] = gt[2][e], sh[4 + e] = gt[3][e];
 #pragma unroll
     for (int i = 0; i < CH_ITEMS; ++i) {
       if (i < i0 || i >= i1) continue;
-      u32x4 o = hreg[i];
-      if (xform) {
+      const unsigned keep = 0u - ((okmask >> i) & 1u);  // padding: zeros of the ACTIVATED tensor
+      u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a0, a1;
-          unpack2bf(hreg[i][e], a0, a1);
-          float y0 = round_bf16(a0 * sc[2 * e] + sh[2 * e]);
-          float y1 = round_bf16(a1 * sc[2 * e + 1] + sh[2 * e + 1]);
-          if (p.gn_silu) {
-            y0 = silu_f(y0);
-            y1 = silu_f(y1);
-          }
-          o[e] = pack2bf(y0, y1);
-        }
-        const unsigned keep = 0u - ((okmask >> i) & 1u);  // padding: zeros of the ACTIVATED tensor (all-ones / zero mask, no branch)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] &= keep;
+      for (int e = 0; e < 4; ++e) {
+        float a0, a1;
+        unpack2bf(hreg[i][e], a0, a1);
+        const float g0 = round_bf16(a0 * sc[2 * e] + sh[2 * e]), g1 = round_bf16(a1 * sc[2 * e + 1] + sh[2 * e + 1]);
+        const unsigned plain = pack2bf(g0, g1), act = pack2bf(silu_f(g0), silu_f(g1));
+        const unsigned t = ((act & sm) | (plain & ~sm)) & keep;
+        o[e] = (t & xm) | (hreg[i][e] & ~xm);
       }
-      if ((inmask >> i) & 1u) *(__attribute__((address_space(3))) u32x4*)(lds + lds_w[i] + (c & 1) * CH_A_SLOT) = o;
+      const unsigned dst = ((inmask >> i) & 1u) ? lds_w0 + i * (64 * CH_ROWB) + slot * CH_A_SLOT : dummy_w;
+      *(__attribute__((address_space(3))) u32x4*)(lds + dst) = o;
     }
   };
 
@@ -197,73 +212,153 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
   for (int kk = 0; kk < 2; ++kk)
     w_lane[kk] = (unsigned)(W_OFF + (wn * NF * 16 + l15) * 128 + (((kk * 4 + q) ^ (l15 >> 1)) << 4));
 
-  // ---- prologue: halo of chunk 0, weights of K-tile 0 (-> LDS) and K-tiles 1, 2 (-> registers) ----
-  // Weight registers: K-tile k travels in set k % 3 -- loaded in iteration k - 3, stored to LDS in iteration k - 1 -- so the loop is
-  // unrolled by three with compile-time set names (a rotation by copies would make every iteration wait for the loads it has
-  // just issued).
+  // ---- prologue: halo of chunk 0, weights of K-tiles 0, 1 (-> LDS slots 0, 1) and 2, 3 (-> registers) ----
+  // Weight registers: K-tile k travels in register set k % 3 -- loaded in iteration k - 4, stored to LDS slot k % 3 in iteration
+  // k - 2 -- so the loops are unrolled by three with compile-time set / slot names (a rotation by copies would make every
+  // iteration wait for the loads it has just issued).
   u32x4 wr0[W_ITEMS], wr1[W_ITEMS], wr2[W_ITEMS];
 #pragma unroll
   for (int j = 0; j < W_ITEMS; ++j) wr0[j] = wr1[j] = wr2[j] = u32x4{0u, 0u, 0u, 0u};
+  constexpr bool in_loop = false;  // (lab ablations leave the prologue alone)
   CH_LOAD_HALO(hreg, 0);
   CH_LOAD_W(wr0, 0);
-  store_halo(0, 0, CH_ITEMS);
-  CH_STORE_W(wr0, 0);
   CH_LOAD_W(wr1, 1);
+  store_halo(0, 0, 0, CH_ITEMS);
+  CH_STORE_W(wr0, 0);
+  CH_STORE_W(wr1, 1);
   CH_LOAD_W(wr2, 2);
+  CH_LOAD_W(wr0, 3);
   __syncthreads();
 
-  // One K-tile.  S: K-tile index, CHUNK: its chunk (LDS halo slot CHUNK & 1), DY / DX: its tap (compile-time: the shifted window is
-  // an immediate offset), WL: the register set that receives K-tile S + 3 (set S % 3), WS: the set holding K-tile S + 1,
-  // HLOAD: issue the halo loads of chunk CHUNK + 1 (clamped), H0 .. H1: halo items of chunk CHUNK + 1 to transform + store
-#define CH_KTILE(S, CHUNK, DY, DX, WL, WS, HLOAD, H0, H1)                                                                       \
-  {                                                                                                                             \
-    const int s_ = uint_(S), c_k = uint_(CHUNK);                                                                                \
-    CH_LOAD_W(WL, s_ + 3);                                                                                                      \
-    if (HLOAD) {                                                                                                                \
-      /* the weight loads stay OLDER than the halo loads: vmcnt retires in order, and K-tile s + 3's weights are stored two     \
-         K-tiles from here -- behind the halo loads they would wait for the halo's HBM latency */                               \
-      __builtin_amdgcn_sched_barrier(0);                                                                                        \
-      CH_LOAD_HALO(hreg, c_k + 1 < n_chunks ? c_k + 1 : n_chunks - 1);                                                          \
+  // fragment sets: F0 = the K = 0..31 half of a K-tile, F1 = the K = 32..63 half
+  bf16x8 wf0[NF], af0[MF], wf1[NF], af1[MF];
+#define CH_READ(WF, AF, WSLOT, ABASE, KK)                                                                                       \
+  if (!((CH_ABL & 2) && in_loop)) do {                                                                                          \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                                           \
+        WF[nf] = *(const __attribute__((address_space(3))) bf16x8*)(lds + w_lane[KK] + (WSLOT) * W_SLOT + nf * 2048);           \
+    _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                                           \
+        AF[mf] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (ABASE) + mf * (18 * CH_ROWB) + (KK) * 64);           \
+  } while (0)
+#define CH_MMA(WF, AF)                                                                                                          \
+  if (!(CH_ABL & 1)) do {                                                                                                       \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                         \
+        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nf], AF[mf], acc[nf][mf], 0, 0, 0);                            \
+  } while (0)
+  // halo window of (chunk, tap): byte offset of halo row (dy * 18 + dx) in the chunk's slot
+#define CH_ABASE(CHUNK, DY, DX) (a_lane + (unsigned)(((CHUNK) & 1) * CH_A_SLOT + ((DY) * 18 + (DX)) * CH_ROWB))
+  CH_READ(wf0, af0, 0, CH_ABASE(0, n_main > 0 ? 0 : 1, n_main > 0 ? 0 : 1), 0);
+
+  // The order the instructions of a K-tile are to be issued in (sched_group_barrier, guide T19): every MFMA is followed by one LDS
+  // fragment read while there are any (2 x (NF + MF) per K-tile), the memory instructions (weight loads, weight stores to LDS, at a
+  // chunk's first tap the halo loads) go behind MFMAs too -- so that a wave's own LDS / memory issue sits in the shadow of its MFMAs
+  // instead of in front of them, and the two waves of a SIMD do not meet in the same phase.
+  // masks: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read
+#if CH_SGB == 1
+#define CH_PIPELINE(HLOAD, NH)                                                                                                  \
+  do {                                                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2 * (NF + MF); ++i_) {                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                        \
+      if ((NH) > 0) __builtin_amdgcn_sched_group_barrier(0x2, 3, 0); /* the halo transform rides along, 3 VALU per MFMA */      \
     }                                                                                                                           \
-    {                                                                                                                           \
-      const unsigned aA = a_lane + (unsigned)((c_k & 1) * CH_A_SLOT);                                                           \
-      const unsigned wS = (unsigned)((s_ & 1) * W_SLOT);                                                                        \
-      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                                        \
-        bf16x8 wf[NF], af[MF];                                                                                                  \
-        _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                                       \
-            wf[nf] = *(const __attribute__((address_space(3))) bf16x8*)(lds + w_lane[kk] + wS + nf * 2048);                     \
-        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                                                                       \
-            af[mf] = *(const __attribute__((address_space(3))) bf16x8*)(lds + aA + ((DY) * 18 + (DX) + mf * 18) * CH_ROWB + kk * 64); \
-        _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)                     \
-            acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[nf][mf], 0, 0, 0);                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < W_ITEMS; ++i_) {                                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                                         \
+      if ((NH) > 0) __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);                                                            \
+    }                                                                                                                           \
+    if (HLOAD) {                                                                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < CH_ITEMS + 4; ++i_) {                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                                       \
       }                                                                                                                         \
     }                                                                                                                           \
-    CH_STORE_W(WS, s_ + 1);                                                                                                     \
-    if ((H1) > (H0) && c_k + 1 < n_chunks) store_halo(c_k + 1, (H0), (H1));                                                     \
-    __syncthreads();                                                                                                            \
+    if ((NH) > 0) {                                                                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2 * NF * MF - 2 * (NF + MF) - 2 * W_ITEMS; ++i_) {                                \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);                                                                        \
+      }                                                                                                                         \
+    }                                                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < W_ITEMS + (NH); ++i_) {                                                             \
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                        \
+    }                                                                                                                           \
+  } while (0)
+#else
+#define CH_PIPELINE(HLOAD, NH) do { } while (0)
+#endif
+  // One K-tile.  S: K-tile index (weights in LDS slot WS3 = S % 3), CHUNK / DY / DX: its chunk and tap, NEXT_ABASE: halo window of
+  // K-tile S + 1 (its weights: slot (WS3 + 1) % 3), WL: the register set that receives K-tile S + 4 (set (WS3 + 1) % 3),
+  // WST: the set holding K-tile S + 2 (-> LDS slot (WS3 + 2) % 3), HLOAD: issue the halo loads of chunk CHUNK + 1 (clamped),
+  // H0 .. H1: halo items of chunk CHUNK + 1 to transform + store
+#define CH_KTILE(S, CHUNK, DY, DX, WS3, NEXT_ABASE, WL, WST, HLOAD, H0, H1)                                                     \
+  {                                                                                                                             \
+    constexpr bool in_loop = true;                                                                                              \
+    const int s_ = uint_(S), c_k = uint_(CHUNK);                                                                                \
+    CH_LOAD_W(WL, s_ + 4);                                                                                                      \
+    if ((HLOAD) && !(CH_ABL & 32)) {                                                                                            \
+      /* the weight loads stay OLDER than the halo loads: vmcnt retires in order, and these weights are stored two K-tiles from \
+         here -- behind the halo loads they would wait for the halo's HBM latency */                                            \
+      if (!CH_SGB) __builtin_amdgcn_sched_barrier(0);                                                                            \
+      CH_LOAD_HALO(hreg, c_k + 1 < n_chunks ? c_k + 1 : n_chunks - 1);                                                          \
+    }                                                                                                                           \
+    CH_READ(wf1, af1, WS3, CH_ABASE(c_k, DY, DX), 1);                                                                           \
+    CH_MMA(wf0, af0);                                                                                                           \
+    /* (behind the last K-tile this fetches a window nobody multiplies: unconditional, so that the K-tile stays one scheduling  \
+       region) */                                                                                                               \
+    CH_READ(wf0, af0, ((WS3) + 1) % 3, (NEXT_ABASE), 0);                                                                        \
+    CH_MMA(wf1, af1);                                                                                                           \
+    CH_STORE_W(WST, ((WS3) + 2) % 3);                                                                                           \
+    /* (unconditional: behind the last chunk the clamped chunk's values go to the idle slot, where nobody reads them) */        \
+    if ((H1) > (H0) && !(CH_ABL & 32)) store_halo((c_k + 1) & 1, c_k + 1 < n_chunks ? c_k + 1 : n_chunks - 1, (H0), (H1));       \
+    CH_PIPELINE(HLOAD, (H1) - (H0));                                                                                            \
+    if (!(CH_ABL & 4)) __syncthreads();                                                                                         \
   }
-  // main chunks: nine taps, K-tile 9 * cc + tap in register set tap % 3; the next chunk's halo is loaded at tap 0 and stored over taps 5 - 7
+  // main chunks: nine taps, K-tile 9 * cc + tap: LDS slot / register set tap % 3; the next chunk's halo is loaded at tap 0 and stored
+  // one item per tap over taps 2 - 7 (visible, behind tap 7's barrier, when tap 8 prefetches the next chunk's first window)
   for (int cc = 0; cc < n_main; ++cc) {
     const int s0 = 9 * cc;
-    CH_KTILE(s0 + 0, cc, 0, 0, wr0, wr1, true, 0, 0)
-    CH_KTILE(s0 + 1, cc, 0, 1, wr1, wr2, false, 0, 0)
-    CH_KTILE(s0 + 2, cc, 0, 2, wr2, wr0, false, 0, 0)
-    CH_KTILE(s0 + 3, cc, 1, 0, wr0, wr1, false, 0, 0)
-    CH_KTILE(s0 + 4, cc, 1, 1, wr1, wr2, false, 0, 0)
-    CH_KTILE(s0 + 5, cc, 1, 2, wr2, wr0, false, 0, 2)
-    CH_KTILE(s0 + 6, cc, 2, 0, wr0, wr1, false, 2, 4)
-    CH_KTILE(s0 + 7, cc, 2, 1, wr1, wr2, false, 4, 6)
-    CH_KTILE(s0 + 8, cc, 2, 2, wr2, wr0, false, 0, 0)
+    // the K-tile behind this chunk's last tap: tap (0, 0) of the next main chunk, or the centre tap of the first shortcut chunk
+    const unsigned nxt = cc + 1 < n_main ? CH_ABASE(cc + 1, 0, 0) : CH_ABASE(cc + 1, 1, 1);
+    CH_KTILE(s0 + 0, cc, 0, 0, 0, CH_ABASE(cc, 0, 1), wr1, wr2, true, 0, 0)
+    CH_KTILE(s0 + 1, cc, 0, 1, 1, CH_ABASE(cc, 0, 2), wr2, wr0, false, 0, 0)
+    CH_KTILE(s0 + 2, cc, 0, 2, 2, CH_ABASE(cc, 1, 0), wr0, wr1, false, 0, 1)
+    CH_KTILE(s0 + 3, cc, 1, 0, 0, CH_ABASE(cc, 1, 1), wr1, wr2, false, 1, 2)
+    CH_KTILE(s0 + 4, cc, 1, 1, 1, CH_ABASE(cc, 1, 2), wr2, wr0, false, 2, 3)
+    CH_KTILE(s0 + 5, cc, 1, 2, 2, CH_ABASE(cc, 2, 0), wr0, wr1, false, 3, 4)
+    CH_KTILE(s0 + 6, cc, 2, 0, 0, CH_ABASE(cc, 2, 1), wr1, wr2, false, 4, 5)
+    CH_KTILE(s0 + 7, cc, 2, 1, 1, CH_ABASE(cc, 2, 2), wr2, wr0, false, 5, 6)
+    CH_KTILE(s0 + 8, cc, 2, 2, 2, nxt, wr0, wr1, false, 0, 0)
   }
-  // shortcut chunks: one K-tile each (centre tap); the next one's halo is loaded and stored inside the K-tile (its latency is exposed:
-  // at most C2 / 64 times per workgroup)
+  // shortcut chunks: one K-tile each (centre tap); the next one's halo is loaded and stored inside the K-tile BEFORE the prefetch of
+  // its first window would need it -- so the prefetch is dropped here: these K-tiles read both halves behind the barrier (their
+  // latency is exposed, at most C2 / 64 times per workgroup)
+#define CH_KTILE_SC(S, CHUNK, WS3, WL, WST)                                                                                     \
+  {                                                                                                                             \
+    constexpr bool in_loop = true;                                                                                              \
+    const int s_ = uint_(S), c_k = uint_(CHUNK);                                                                                \
+    CH_LOAD_W(WL, s_ + 4);                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    CH_LOAD_HALO(hreg, c_k + 1 < n_chunks ? c_k + 1 : n_chunks - 1);                                                            \
+    CH_READ(wf1, af1, WS3, CH_ABASE(c_k, 1, 1), 1);                                                                             \
+    CH_MMA(wf0, af0);                                                                                                           \
+    CH_MMA(wf1, af1);                                                                                                           \
+    CH_STORE_W(WST, ((WS3) + 2) % 3);                                                                                           \
+    if (c_k + 1 < n_chunks) store_halo((c_k + 1) & 1, c_k + 1, 0, CH_ITEMS);                                                    \
+    __syncthreads();                                                                                                            \
+    if (s_ + 1 < nkt) CH_READ(wf0, af0, ((WS3) + 1) % 3, CH_ABASE(c_k + 1, 1, 1), 0);                                           \
+  }
   for (int j = 0; j < n_sc; j += 3) {
     const int s0 = 9 * n_main + j, c0 = n_main + j;
-    CH_KTILE(s0, c0, 1, 1, wr0, wr1, true, 0, CH_ITEMS)
-    if (j + 1 < n_sc) CH_KTILE(s0 + 1, c0 + 1, 1, 1, wr1, wr2, true, 0, CH_ITEMS)
-    if (j + 2 < n_sc) CH_KTILE(s0 + 2, c0 + 2, 1, 1, wr2, wr0, true, 0, CH_ITEMS)
+    CH_KTILE_SC(s0, c0, 0, wr1, wr2)
+    if (j + 1 < n_sc) CH_KTILE_SC(s0 + 1, c0 + 1, 1, wr2, wr0)
+    if (j + 2 < n_sc) CH_KTILE_SC(s0 + 2, c0 + 2, 2, wr0, wr1)
   }
 #undef CH_KTILE
+#undef CH_KTILE_SC
+#undef CH_PIPELINE
+#undef CH_READ
+#undef CH_MMA
+#undef CH_ABASE
 #undef CH_LOAD_W
 #undef CH_STORE_W
 #undef CH_LOAD_HALO
@@ -285,9 +380,10 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
         if (p.raw) *(u32x2*)(p.raw + pix * 4) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         for (int e = 0; e < 3; ++e) {
           if (e >= p.out_channels) break;
-          const float im = fminf(fmaxf(v[e] * 0.5f + 0.5f, 0.f), 1.f);  // __init__.py:581-584
+          // the arithmetic of dk_image_post_kernel: bf16 products like the reference's (__init__.py:581-584; :525-526 truncation)
+          const float im = fminf(fmaxf(round_bf16(v[e] * 0.5f + 0.5f), 0.f), 1.f);
           if (p.img) p.img[pix * 3 + e] = im;
-          if (p.u8) p.u8[pix * 3 + e] = (unsigned char)(im * 255.0f);     // :525-526 (truncation)
+          if (p.u8) p.u8[pix * 3 + e] = (unsigned char)round_bf16(im * 255.0f);
         }
       }
     }
@@ -325,13 +421,24 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
     float ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+    // the residual rows of all eight passes up front: one memory latency instead of eight (the compiler cannot move a load of
+    // `res` above a store to `y` -- the two may alias for all it knows)
+    u32x4 resv[8];
+    if (p.res) {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 8 + rr;
+        const size_t pix = ((size_t)b * p.H + py0 + wm * MF + (row >> 4)) * p.W + px0 + (row & 15);
+        resv[pass] = *(const u32x4*)(p.res + pix * (size_t)p.ldr + ocol);
+      }
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int row = pass * 8 + rr;  // pixel inside the wave tile: pixel row row >> 4, x = row & 15
       const size_t pix = ((size_t)b * p.H + py0 + wm * MF + (row >> 4)) * p.W + px0 + (row & 15);
       u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)(lds + img0 + row * 128 + ((rc ^ (row & 7)) << 4));
       if (p.res) {
-        const u32x4 rv = *(const u32x4*)(p.res + pix * (size_t)p.ldr + ocol);
+        const u32x4 rv = resv[pass];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v0, v1, r0, r1;
@@ -340,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
           sv[e] = pack2bf(v0 + r0, v1 + r1);
         }
       }
-      *(u32x4*)(p.y + pix * (size_t)p.ldy + ocol) = sv;
+      if (!(CH_ABL & 64) || p.ldy == -1) *(u32x4*)(p.y + pix * (size_t)p.ldy + ocol) = sv;
       if (p.stats_out) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -410,7 +517,7 @@ int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream) {
   const bool img = p.img != nullptr || p.u8 != nullptr || p.raw != nullptr;
   DK_REQUIRE(dk_conv_halo_eligible(p, img), "conv_halo: shape / alignment not supported (H, W multiples of 16; C multiple of 64; O multiple of 128, or <= 4 for the image tail)");
   static bool attr_set = false;
-  constexpr int LDS128 = 2 * CH_A_SLOT + 2 * 128 * 128, LDS16 = 2 * CH_A_SLOT + 2 * 16 * 128;
+  constexpr int LDS128 = 2 * CH_A_SLOT + 3 * 128 * 128 + 8192, LDS16 = 2 * CH_A_SLOT + 3 * 16 * 128 + 8192;  // (+ the dummy store zone)
   if (!attr_set) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_conv_halo_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_conv_halo_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS16));

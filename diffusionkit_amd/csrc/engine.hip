@@ -26,8 +26,9 @@ int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the que
 // memory channels (linear2 of FLUX: 369 -> 345 us with the padded pitch, profiles/r01_gemm_lab_pitch.log).
 int g_dk_pitch_min_k = 8192;
 // dk_tune_set("conv_halo", v): the VAE's norm -> silu -> conv stages on the halo-staged kernel with the GroupNorm applied on load
-// (conv_halo.hip): -1 (default) where the output has fewer than 256 channels (the HBM-bound high-resolution stage and conv_out; the
-// 256 / 512-channel stages stay on the 256 x 256 implicit-GEMM kernel behind a GroupNorm-apply pass), 0 never, 1 wherever the shape allows
+// (conv_halo.hip): -1 (default) / 1 wherever the shape allows (measured: decode 15.1 -> 12.5 ms, against 13.0 ms when only the
+// stages with fewer than 256 output channels use it -- the 256 / 512-channel convs are ~7 % slower than on the 256 x 256 implicit-GEMM
+// kernel, but lose their GroupNorm-apply passes), 2 only below 256 output channels, 0 never
 int g_dk_conv_halo = -1;
 extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
@@ -1186,7 +1187,7 @@ struct VaeRun {
   bool halo_stage(int H, int Wd, int Cin, int Cout) const {
     if (g_dk_conv_halo == 0 || H % 16 != 0 || Wd % 16 != 0 || Cin % 64 != 0 || Cout % 128 != 0) return false;
     if ((size_t)H * Wd * (Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return false;
-    return g_dk_conv_halo > 0 || Cout < 256;
+    return g_dk_conv_halo != 2 || Cout < 256;
   }
   // the (scale | shift) table of GroupNorm `name` over tensor x: from the partials the producing conv left, or a statistics pass
   int gn_table(const bf16_t* x, long HW, int C, const std::string& name, float* ss) {
@@ -1317,7 +1318,21 @@ extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int3
     if (j > 0) {
       H *= 2; W *= 2;
       R.n_part = 0;
-      DK_TRY(R.conv(cur, nxt, H, W, C, C, "up_blocks." + std::to_string(j) + ".upsample", 1, nullptr, C)); std::swap(cur, nxt);
+      const std::string up = "up_blocks." + std::to_string(j) + ".upsample";
+      if (g_dk_conv_halo != 3 && R.halo_stage(H, W, C, C)) {
+        // the upsampling conv (vae.py:20-25,146) on the halo kernel too: nearest-x2 folded into the halo addressing, no norm in
+        // front of it, and the statistics of its output for the next block's first GroupNorm
+        ConvHaloParams c;
+        memset(&c, 0, sizeof(c));
+        c.x = cur; c.w = R.W(up + ".weight"); c.bias = R.W(up + ".bias"); c.y = nxt; c.stats_out = v->gn; c.G_out = cf.resnet_groups;
+        c.B = batch; c.H = H; c.W = W; c.C = C; c.O = C; c.ups = 1; c.ldw = 9 * C; c.ldy = C;
+        if (R.rc) return R.rc;
+        DK_TRY(dk_launch_conv_halo(c, st));
+        R.n_part = (H / 16) * (W / 16);
+      } else {
+        DK_TRY(R.conv(cur, nxt, H, W, C, C, up, 1, nullptr, C));
+      }
+      std::swap(cur, nxt);
     }
   }
   if (g_dk_conv_halo != 0 && H % 16 == 0 && W % 16 == 0 && C % 64 == 0 && cf.out_channels <= 4 && (size_t)H * W * C * 2 < (1ull << 31)) {

@@ -63,13 +63,15 @@ __global__ __launch_bounds__(256) void dk_gn_partial_kernel(const bf16_t* __rest
     partial[((size_t)b * nchunk + chunk) * 2 * G + tid] = acc;
   }
 }
-// one wave per (batch, group): lanes stride over the chunk partials, fixed-order shuffle tree (double)
-__global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
-                                                            float* __restrict__ mean_rstd, const bf16_t* __restrict__ gamma,
-                                                            const bf16_t* __restrict__ beta, int C, float* __restrict__ scale_shift) {
-  const int b = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
+// one workgroup of 256 threads per (batch, group): threads stride over the chunk partials (up to one per 16 x 16 output tile when a
+// fused conv produced them: 4096 at 1024 x 1024), then a fixed-order tree (double) -- wave shuffles, four wave results through LDS
+__global__ __launch_bounds__(256) void dk_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int G, double count, float eps,
+                                                             float* __restrict__ mean_rstd, const bf16_t* __restrict__ gamma,
+                                                             const bf16_t* __restrict__ beta, int C, float* __restrict__ scale_shift) {
+  __shared__ double red[8];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s = 0.0, q = 0.0;
-  for (int c = lane; c < nchunk; c += 64) {
+  for (int c = tid; c < nchunk; c += 256) {
     s += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g];
     q += (double)partial[((size_t)b * nchunk + c) * 2 * G + 2 * g + 1];
   }
@@ -78,21 +80,22 @@ __global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restr
     s += __shfl_xor(s, o, 64);
     q += __shfl_xor(q, o, 64);
   }
-  if (lane == 0) {
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
-    mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (lane == 0) red[wave] = s, red[4 + wave] = q;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  q = (red[4] + red[5]) + (red[6] + red[7]);
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0) {
+    mean_rstd[((size_t)b * G + g) * 2] = mf;
+    mean_rstd[((size_t)b * G + g) * 2 + 1] = rf;
   }
   if (scale_shift != nullptr) {
     // the per-channel pair dk_gn_apply_kernel builds in LDS (same fp32 expressions), for consumers that apply the norm on load
-    const double mean = __shfl(s, 0, 64) / count;
-    double var = __shfl(q, 0, 64) / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
     const int cpg = C / G;
-    for (int c = lane; c < cpg; c += 64) {
+    for (int c = tid; c < cpg; c += 256) {
       const int ch = g * cpg + c;
       const float sc = rf * bf2f(gamma[ch]);
       scale_shift[(size_t)b * 2 * C + ch] = sc;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void dk_gn_finalize_kernel(const float* __restr
 int dk_launch_groupnorm_finalize(const float* partial, int nchunk, int B, int G, double count, float eps, float* mean_rstd,
                                  const bf16_t* gamma, const bf16_t* beta, int C, float* scale_shift, hipStream_t stream) {
   DK_REQUIRE(G >= 1 && nchunk >= 1 && (scale_shift == nullptr || (gamma && beta && C % G == 0)), "groupnorm finalize arguments");
-  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B * G), dim3(64), 0, stream, partial, nchunk, G, count, eps, mean_rstd, gamma, beta, C,
+  hipLaunchKernelGGL(dk_gn_finalize_kernel, dim3(B * G), dim3(256), 0, stream, partial, nchunk, G, count, eps, mean_rstd, gamma, beta, C,
                      scale_shift);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

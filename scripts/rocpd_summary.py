@@ -28,7 +28,7 @@ def main():
     print(f"\ntotal kernel time: {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
     if "--by-grid" in sys.argv:
         rows = cur.execute(
-            "select name, grid_x, count(*), sum(duration), avg(duration) from kernels where name like '%gemm%' or name like '%attn%' "
+            "select name, grid_x, count(*), sum(duration), avg(duration) from kernels where name like '%gemm%' or name like '%attn%' or name like '%conv%' or name like '%gn_%' "
             "group by name, grid_x order by sum(duration) desc").fetchall()
         print("\n| kernel | grid_x (threads) | calls | total ms | avg us |\n|---|---|---|---|---|")
         for name, grid, n, tot, avg in rows[:40]:

@@ -544,6 +544,19 @@ def test_conv3x3_gn_halo(dev, B, H, W, C, O, res, sc, gn):
     assert rel_l2(t_pass.cpu(), t_part.cpu()) < 1e-5
 
 
+def test_conv3x3_halo_upsample(dev):
+    """the upsampling conv (vae.py:20-25,146) on the halo kernel: the nearest-x2 view folded into the halo addressing, no norm"""
+    from diffusionkit_amd import ops
+    B, Hs, Ws, C, O = 2, 16, 24, 128, 256
+    x = randn(B, Hs, Ws, C, seed=96)
+    w = randn(O, 3, 3, C, seed=97, scale=0.05)
+    b = randn(O, seed=98, scale=0.1)
+    ref = ov.conv2d_nhwc(ov.upsample_nearest(x), w, b, Prec())
+    y = ops.conv3x3_gn(g(x, dev), g(w, dev).reshape(O, -1), g(b, dev), gn_table=None, upsample=True)
+    assert y.shape == ref.shape == (B, 2 * Hs, 2 * Ws, O)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+
+
 def test_conv_out_image_tail_halo(dev):
     """conv_norm_out -> silu -> conv_out -> clip / uint8 (vae.py:381,384,397-399; __init__.py:581-584,525-526) in one launch"""
     from diffusionkit_amd import ops
@@ -559,8 +572,8 @@ def test_conv_out_image_tail_halo(dev):
     tab = ops.groupnorm_table(xd, g(gamma, dev), g(beta, dev), G, eps)
     img, u8, raw = ops.conv3x3_gn(xd, g(w, dev).reshape(3, -1), g(b, dev), gn_table=tab, image=True)
     assert rel_l2(ref, raw[..., :3].float()) < TOL_SINGLE_OP
-    want = torch.clip(raw[..., :3].float() / 2 + 0.5, 0, 1)
-    assert torch.equal(img, want) and torch.equal(u8, (want * 255).to(torch.uint8))
+    want = torch.clip((raw[..., :3].float() / 2 + 0.5).to(BF).float(), 0, 1)  # bf16 products, as dk_image_post_kernel and the reference
+    assert torch.equal(img, want) and torch.equal(u8, (want.to(BF) * 255).to(BF).to(torch.uint8))
     assert torch.all(raw[..., 3].float() == 0)
 
 
