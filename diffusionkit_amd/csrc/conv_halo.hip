@@ -33,9 +33,10 @@
 typedef __attribute__((address_space(3))) char lds_c;
 
 #ifndef CH_SGB
-#define CH_SGB 1  // sched_group_barrier pipeline inside a K-tile: 1 = one LDS read / memory instruction behind every MFMA (0: the compiler's own
-                  // order -- MFMAs in runs of 8-16 and the reads in front of them, both waves of a SIMD in the same phase: the MFMA time and
-                  // everything else then add up instead of overlapping, profiles/r03_conv_halo_ablations.md)
+#define CH_SGB 0  // lab: 1 = a sched_group_barrier pipeline inside a K-tile (one LDS read / memory instruction / a few VALU of the halo
+                  // transform behind every MFMA, guide T19) instead of the compiler's own order.  Measured flat (+-2 %,
+                  // profiles/r03_conv_halo_ablations.md): the order of a wave's instructions is not what keeps the MFMA time and
+                  // everything else from overlapping.
 #endif
 #ifndef CH_ABL
 #define CH_ABL 0  // lab only (scripts/build_halo_abl.sh), bit mask of what the K loop leaves out: 1 the MFMAs, 2 the fragment reads, 4 the
@@ -170,29 +171,28 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
     gt[2] = *(const f32x4*)(g_ + gsh_off), gt[3] = *(const f32x4*)(g_ + gsh_off + 4);                                         \
   } while (0)
   u32x4 hreg[CH_ITEMS];
-  // registers (hreg) -> (GroupNorm-apply + SiLU) -> LDS halo slot `slot`; items i0 .. i1-1 of chunk c.  STRAIGHT-LINE code (masks and
-  // selects instead of branches, a dummy LDS zone behind the weight slots for the 480 threads without a sixth item): inside a K-tile
-  // it has to sit in the same scheduling region as the MFMAs it is to overlap with.
+  // registers (hreg) -> (GroupNorm-apply + SiLU) -> LDS halo slot `slot`; items i0 .. i1-1 of chunk c (the 480 threads without a sixth
+  // item store theirs to a dummy LDS zone behind the weight slots: no divergent branch around the store)
   const unsigned dummy_w = (unsigned)(W_OFF + 3 * W_SLOT + tid * 16);
   auto store_halo = [&](int slot, int c, int i0, int i1) {
     const bool xform = gss != nullptr && c < n_main && !((CH_ABL & 8) && c > 0);
-    const unsigned xm = xform ? 0xFFFFFFFFu : 0u, sm = p.gn_silu ? 0xFFFFFFFFu : 0u;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) sc[e] = gt[0][e], sc[4 + e] = gt[1][e], sh[e] = gt[2][e], sh[4 + e] = gt[3][e];
 #pragma unroll
     for (int i = 0; i < CH_ITEMS; ++i) {
       if (i < i0 || i >= i1) continue;
-      const unsigned keep = 0u - ((okmask >> i) & 1u);  // padding: zeros of the ACTIVATED tensor
-      u32x4 o;
+      u32x4 o = hreg[i];
+      if (xform) {
+        const unsigned keep = 0u - ((okmask >> i) & 1u);  // padding: zeros of the ACTIVATED tensor
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a0, a1;
-        unpack2bf(hreg[i][e], a0, a1);
-        const float g0 = round_bf16(a0 * sc[2 * e] + sh[2 * e]), g1 = round_bf16(a1 * sc[2 * e + 1] + sh[2 * e + 1]);
-        const unsigned plain = pack2bf(g0, g1), act = pack2bf(silu_f(g0), silu_f(g1));
-        const unsigned t = ((act & sm) | (plain & ~sm)) & keep;
-        o[e] = (t & xm) | (hreg[i][e] & ~xm);
+        for (int e = 0; e < 4; ++e) {
+          float a0, a1;
+          unpack2bf(hreg[i][e], a0, a1);
+          float g0 = round_bf16(a0 * sc[2 * e] + sh[2 * e]), g1 = round_bf16(a1 * sc[2 * e + 1] + sh[2 * e + 1]);
+          if (p.gn_silu) g0 = silu_f(g0), g1 = silu_f(g1);
+          o[e] = pack2bf(g0, g1) & keep;
+        }
       }
       const unsigned dst = ((inmask >> i) & 1u) ? lds_w0 + i * (64 * CH_ROWB) + slot * CH_A_SLOT : dummy_w;
       *(__attribute__((address_space(3))) u32x4*)(lds + dst) = o;
@@ -308,25 +308,24 @@ __global__ __launch_bounds__(512, 2) void dk_conv_halo_kernel(ConvHaloParams p) 
     CH_READ(wf0, af0, ((WS3) + 1) % 3, (NEXT_ABASE), 0);                                                                        \
     CH_MMA(wf1, af1);                                                                                                           \
     CH_STORE_W(WST, ((WS3) + 2) % 3);                                                                                           \
-    /* (unconditional: behind the last chunk the clamped chunk's values go to the idle slot, where nobody reads them) */        \
-    if ((H1) > (H0) && !(CH_ABL & 32)) store_halo((c_k + 1) & 1, c_k + 1 < n_chunks ? c_k + 1 : n_chunks - 1, (H0), (H1));       \
+    if ((H1) > (H0) && c_k + 1 < n_chunks && !(CH_ABL & 32)) store_halo((c_k + 1) & 1, c_k + 1, (H0), (H1));                    \
     CH_PIPELINE(HLOAD, (H1) - (H0));                                                                                            \
     if (!(CH_ABL & 4)) __syncthreads();                                                                                         \
   }
   // main chunks: nine taps, K-tile 9 * cc + tap: LDS slot / register set tap % 3; the next chunk's halo is loaded at tap 0 and stored
-  // one item per tap over taps 2 - 7 (visible, behind tap 7's barrier, when tap 8 prefetches the next chunk's first window)
+  // two items per tap over taps 5 - 7 (visible, behind tap 7's barrier, when tap 8 prefetches the next chunk's first window)
   for (int cc = 0; cc < n_main; ++cc) {
     const int s0 = 9 * cc;
     // the K-tile behind this chunk's last tap: tap (0, 0) of the next main chunk, or the centre tap of the first shortcut chunk
     const unsigned nxt = cc + 1 < n_main ? CH_ABASE(cc + 1, 0, 0) : CH_ABASE(cc + 1, 1, 1);
     CH_KTILE(s0 + 0, cc, 0, 0, 0, CH_ABASE(cc, 0, 1), wr1, wr2, true, 0, 0)
     CH_KTILE(s0 + 1, cc, 0, 1, 1, CH_ABASE(cc, 0, 2), wr2, wr0, false, 0, 0)
-    CH_KTILE(s0 + 2, cc, 0, 2, 2, CH_ABASE(cc, 1, 0), wr0, wr1, false, 0, 1)
-    CH_KTILE(s0 + 3, cc, 1, 0, 0, CH_ABASE(cc, 1, 1), wr1, wr2, false, 1, 2)
-    CH_KTILE(s0 + 4, cc, 1, 1, 1, CH_ABASE(cc, 1, 2), wr2, wr0, false, 2, 3)
-    CH_KTILE(s0 + 5, cc, 1, 2, 2, CH_ABASE(cc, 2, 0), wr0, wr1, false, 3, 4)
-    CH_KTILE(s0 + 6, cc, 2, 0, 0, CH_ABASE(cc, 2, 1), wr1, wr2, false, 4, 5)
-    CH_KTILE(s0 + 7, cc, 2, 1, 1, CH_ABASE(cc, 2, 2), wr2, wr0, false, 5, 6)
+    CH_KTILE(s0 + 2, cc, 0, 2, 2, CH_ABASE(cc, 1, 0), wr0, wr1, false, 0, 0)
+    CH_KTILE(s0 + 3, cc, 1, 0, 0, CH_ABASE(cc, 1, 1), wr1, wr2, false, 0, 0)
+    CH_KTILE(s0 + 4, cc, 1, 1, 1, CH_ABASE(cc, 1, 2), wr2, wr0, false, 0, 0)
+    CH_KTILE(s0 + 5, cc, 1, 2, 2, CH_ABASE(cc, 2, 0), wr0, wr1, false, 0, 2)
+    CH_KTILE(s0 + 6, cc, 2, 0, 0, CH_ABASE(cc, 2, 1), wr1, wr2, false, 2, 4)
+    CH_KTILE(s0 + 7, cc, 2, 1, 1, CH_ABASE(cc, 2, 2), wr2, wr0, false, 4, 6)
     CH_KTILE(s0 + 8, cc, 2, 2, 2, nxt, wr0, wr1, false, 0, 0)
   }
   // shortcut chunks: one K-tile each (centre tap); the next one's halo is loaded and stored inside the K-tile BEFORE the prefetch of

@@ -9,6 +9,9 @@ import torch
 from diffusionkit_amd import ops
 
 dev = torch.device("cuda", 0)
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):
+    k, v = kv.split("=")
+    ops.tune(k, int(v))
 shapes = [("128->128 @1024^2", 1024, 1024, 128, 128), ("512->512 @256^2", 256, 256, 512, 512), ("256->256 @512^2", 512, 512, 256, 256),
           ("512->512 @128^2", 128, 128, 512, 512)]
 if os.environ.get("SHAPES"):
@@ -33,4 +36,4 @@ for name, H, W, C, O in shapes:
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
     out.append(f"{name}: {best * 1e3:7.1f} us {2.0 * H * W * 9 * C * O / best / 1e9:7.1f} TF")
-print(os.environ.get("DK_HIP_LIB", "default lib").split("/")[-2] if os.environ.get("DK_HIP_LIB") else "default", " | ".join(out), flush=True)
+print(os.environ.get("DK_HIP_LIB", "default lib").split("/")[-2] if os.environ.get("DK_HIP_LIB") else "default", os.environ.get("TUNE", ""), " | ".join(out), flush=True)
