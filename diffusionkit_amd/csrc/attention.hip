@@ -8,11 +8,12 @@
 // Layout: q/k/v are read in place from the token-major projection output (row stride ld, head h at column h*D), the output is
 // written token-major so the o-projection GEMM consumes it directly -- no [B,H,S,D] transposes exist anywhere.
 //
-// Kernels: attention2.hip (VALU-lean, deferred rescale; 4 / 8 / 7 waves; the only one with a score bias) and attention3.hip
-// (two key tiles in flight per wave).  The first-generation kernel of round 1 is gone (git history).
+// Kernels: attention2.hip (VALU-lean, deferred rescale, 4 waves of 32 queries; the only one with a score bias) and attention3.hip
+// (two key tiles in flight per wave, 8 waves, D = 128).  Round 3 pruned the variants whose A/B is settled (profiles/r01_attention_lab.md,
+// r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
 #include "dk_kernels.h"
 
-extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 / 5 / 6 = dk_attn2 with 4 / 8 / 7 waves; 7 / 8 = dk_attn3 with 8 / 4 waves
+extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3 (8 waves, D = 128 only)
 
 // Hand-off workspace of the balanced form of dk_attn3_fwd_kernel for the launches this host thread enqueues (an engine call sets
 // it to its own engine's region, dk_attention_set_workspace to a caller's buffer; null = plain grids only)
@@ -38,16 +39,15 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   int rc = 0;
   switch (mode) {
     case 4: rc = dk_launch_attention2(p, 4, stream); break;
-    case 5: rc = dk_launch_attention2(p, 8, stream); break;
-    case 6: rc = dk_launch_attention2(p, 7, stream); break;
-    case 7: rc = dk_launch_attention3(p, 8, stream); break;  // software-pipelined kernel (attention3.hip), 8 / 4 waves
-    case 8: rc = dk_launch_attention3(p, 4, stream); break;
-    default: DK_REQUIRE(false, "unknown attention variant");
+    case 7:  // software-pipelined kernel (attention3.hip); D = 64 has no such form: the lean kernel
+      rc = p.D == 128 ? dk_launch_attention3(p, 8, stream) : dk_launch_attention2(p, 4, stream);
+      break;
+    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 7: pipelined kernel)");
   }
   dk_prof_end(stream);
   if (rc) return rc;
   DK_CHECK_HIP(hipGetLastError());
-  if (p.O8 != nullptr && mode != 7 && mode != 8) {
+  if (p.O8 != nullptr && !(mode == 7 && p.D == 128)) {
     // only the pipelined kernel writes the MX-fp8 copy itself: quantise the bf16 output behind the others
     Mx8Out o8{p.O8, p.O8_scales, p.o8_ld, p.o8_nblk, 0, p.B * p.S, 0, 0};
     return dk_launch_quantize_mx8(p.O, p.ldo, p.B * p.S, 0, p.B * p.S, p.H * p.D, o8, stream);

@@ -317,15 +317,10 @@ int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
                "attention bias: row stride must be a multiple of 64 >= S, 8-byte aligned");
     return p.D == 128 ? launch_attn2<128, 4, true>(p, stream) : launch_attn2<64, 4, true>(p, stream);
   }
+  DK_REQUIRE(waves == 4, "attention2: 4 waves per workgroup (the 8- and 7-wave forms were pruned in round 3)");
   if (p.qn_a != nullptr || p.q_rope != nullptr) {  // query-side QKNorm / RoPE fused into the Q load (MMDiT call sites)
     DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
-    if (p.D == 128) return waves == 8 ? launch_attn2<128, 8, false, true>(p, stream) : launch_attn2<128, 4, false, true>(p, stream);
-    return waves == 8 ? launch_attn2<64, 8, false, true>(p, stream) : launch_attn2<64, 4, false, true>(p, stream);
+    return p.D == 128 ? launch_attn2<128, 4, false, true>(p, stream) : launch_attn2<64, 4, false, true>(p, stream);
   }
-  if (p.D == 128) {
-    if (waves == 8) return launch_attn2<128, 8>(p, stream);
-    if (waves == 7) return launch_attn2<128, 7>(p, stream);
-    return launch_attn2<128, 4>(p, stream);
-  }
-  return waves == 8 ? launch_attn2<64, 8>(p, stream) : launch_attn2<64, 4>(p, stream);
+  return p.D == 128 ? launch_attn2<128, 4>(p, stream) : launch_attn2<64, 4>(p, stream);
 }

@@ -500,16 +500,12 @@ size_t dk_attention_balance_workspace_bytes() {
   return (size_t)(n_cu + 1) * DK3_SLOT_BYTES + 4096;
 }
 
-// waves: 8 or 4 per workgroup; no score bias (the text encoders keep dk_attn2_fwd_kernel)
+// 8 waves per workgroup, D = 128; no score bias (the text encoders keep dk_attn2_fwd_kernel)
 int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream) {
   DK_REQUIRE(p.bias == nullptr, "attention3: no score-bias variant");
+  DK_REQUIRE(p.D == 128 && waves == 8, "attention3: head_dim 128, 8 waves (the other forms were pruned in round 3)");
   DK_REQUIRE((size_t)p.S * p.ld * 2 < (1ull << 32), "attention3: one batch row of QKV must span < 4 GiB");
   const bool qfuse = p.qn_a != nullptr || p.q_rope != nullptr;
   if (qfuse) DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
-  if (p.D == 128) {
-    if (waves == 8) return qfuse ? launch_attn3<128, 8, true>(p, stream) : launch_attn3<128, 8, false>(p, stream);
-    return qfuse ? launch_attn3<128, 4, true>(p, stream) : launch_attn3<128, 4, false>(p, stream);
-  }
-  if (waves == 8) return qfuse ? launch_attn3<64, 8, true>(p, stream) : launch_attn3<64, 8, false>(p, stream);
-  return qfuse ? launch_attn3<64, 4, true>(p, stream) : launch_attn3<64, 4, false>(p, stream);
+  return qfuse ? launch_attn3<128, 8, true>(p, stream) : launch_attn3<128, 8, false>(p, stream);
 }

@@ -1,5 +1,5 @@
 """Attention kernel A/B (lab): dk_attention_bf16 under dk_tune_set("attn", mode) on the bench shapes, interleaved rounds in one
-process (guide rule 24).  modes: 5 = dk_attn2 8 waves (round-1 default for D = 128), 4 = dk_attn2 4 waves, 7 / 8 = dk_attn3 8 / 4 waves."""
+process (guide rule 24).  modes: 4 = dk_attn2 (lean kernel, 4 waves), 7 = dk_attn3 (pipelined, 8 waves, D = 128), 7b = its balanced form."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from diffusionkit_amd import ops
 dev = torch.device("cuda", 0)
 shapes = [("flux B1 S4352 D128", 1, 24, 4352, 128), ("flux-dev B1 S4608 D128", 1, 24, 4608, 128), ("sd3 B2 S4685 D64", 2, 24, 4096 + 589, 64),
           ("flux B4", 4, 24, 4352, 128)]
-modes = sys.argv[1:] or ["5", "7", "7b", "4", "8"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
+modes = sys.argv[1:] or ["7", "7b", "4"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
 ws = ops.attention_workspace(dev)
 if os.environ.get("ATTN_SHAPES"):
     shapes = shapes[:int(os.environ["ATTN_SHAPES"])]
