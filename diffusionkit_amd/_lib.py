@@ -109,6 +109,8 @@ SIGNATURES = {
     "dk_conv3x3_gn_bf16": (_i32, [C.POINTER(dk_conv_gn_desc), _vp]),
     "dk_groupnorm_table_bf16": (_i32, [_vp, _i32, C.c_int64, _i32, _i32, _vp, _vp, C.c_float, _vp, _i32, _vp, _vp]),
     "dk_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "dk_attention_d512_tp": (_i32, [_i32]),
+    "dk_attention_d512_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "dk_attention_bias_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i32, _vp]),
     "dk_embedding_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dk_layernorm_bf16": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp]),

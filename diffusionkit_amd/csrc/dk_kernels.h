@@ -163,6 +163,17 @@ int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream);  // attention3.hip (two tiles in flight per wave; no score bias)
 
+// ---- single-head D = 512 attention of the VAE's mid block (attention512.hip) -------------------------------
+struct Attn512Params {
+  const bf16_t* Q;   // [B, T, ld]
+  const bf16_t* K;   // [B, T, ld]
+  const bf16_t* Vt;  // TRANSPOSED values: [B, 512, Tp], rows zero-padded beyond T (dk_launch_transpose with ldy = Tp)
+  bf16_t* O;         // [B, T, ldo]
+  int T, Tp, B, ld, ldo;
+  float scale;
+};
+int dk_launch_attention512(const Attn512Params& p, hipStream_t stream);
+
 // ---- text-conditioning kernels (text_ops.hip) ---------------------------------------------------
 int dk_launch_embedding(const bf16_t* table, const int* ids, const bf16_t* pos, int pos_rows, bf16_t* out, float* out_f32, int n, int dim,
                         int vocab, hipStream_t stream);

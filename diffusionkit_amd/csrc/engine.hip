@@ -30,6 +30,9 @@ int g_dk_pitch_min_k = 8192;
 // stages with fewer than 256 output channels use it -- the 256 / 512-channel convs are ~7 % slower than on the 256 x 256 implicit-GEMM
 // kernel, but lose their GroupNorm-apply passes), 2 only below 256 output channels, 0 never
 int g_dk_conv_halo = -1;
+// dk_tune_set("vae_attn", v): the mid block's attention (512 channels) on the flash kernel of attention512.hip (1, default) or in the
+// reference's materialised form -- scores GEMM, row softmax, transpose, P.V GEMM (0)
+int g_dk_vae_attn = 1;
 extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
@@ -42,6 +45,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   if (strcmp(key, "conv_halo") == 0) { g_dk_conv_halo = value; return 0; }
+  if (strcmp(key, "vae_attn") == 0) { g_dk_vae_attn = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }
@@ -120,6 +124,26 @@ extern "C" int dk_attention_bias_bf16(const void* q, const void* k, const void* 
   p.B = B; p.H = H; p.S = S; p.D = D; p.ld = ld; p.ldo = ldo; p.scale = scale;
   p.bias = (const bf16_t*)bias; p.bias_head_stride = (long)bias_head_stride; p.ldb = ldb;
   return dk_launch_attention(p, S_(stream));
+}
+extern "C" int32_t dk_attention_d512_tp(int32_t T) { return (int32_t)align_up((size_t)(T > 0 ? T : 0), 64); }
+// transpose of every image's V into [512, Tp] rows (zero-padded), then the flash kernel
+static int attention_d512(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int T, int ld, int ldo, float scale,
+                          bf16_t* vt, hipStream_t st) {
+  DK_REQUIRE(ld == 512, "attention_d512: q / k / v rows of exactly 512 columns (the transpose reads dense [T, 512] matrices)");
+  const int Tp = dk_attention_d512_tp(T);
+  for (int b = 0; b < B; ++b) {
+    const int rc = dk_launch_transpose(v + (size_t)b * T * ld, vt + (size_t)b * 512 * Tp, T, 512, st, Tp);
+    if (rc) return rc;
+  }
+  Attn512Params a;
+  a.Q = q; a.K = k; a.Vt = vt; a.O = out; a.T = T; a.Tp = Tp; a.B = B; a.ld = ld; a.ldo = ldo; a.scale = scale;
+  return dk_launch_attention512(a, st);
+}
+extern "C" int dk_attention_d512_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T, int32_t ld, int32_t ldo,
+                                      float scale, void* vt_scratch, void* stream) {
+  DK_REQUIRE(q && k && v && out && vt_scratch && B > 0 && T > 0, "null / empty argument");
+  return attention_d512((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, B, T, ld, ldo, scale, (bf16_t*)vt_scratch,
+                        S_(stream));
 }
 extern "C" int dk_embedding_bf16(const void* table, const int32_t* ids, const void* pos, int32_t pos_rows, void* out_bf16, float* out_f32,
                                  int32_t n, int32_t dim, int32_t vocab, void* stream) {
@@ -1135,8 +1159,9 @@ static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
   v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
-  v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
-  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
+  v->Vt = (bf16_t*)c.take((size_t)B * align_up(tok, 64) * Cm * 2);  // (the flash form transposes every image's V up front)
+  // the materialised score matrix of the general path; a 512-channel mid block runs the flash kernel (attention512.hip) and needs none
+  v->SCORES = (bf16_t*)c.take((Cm == 512 && g_dk_vae_attn != 0) ? 0 : tok * align_up(tok, 64) * 2);
   {
     // statistics scratch: up to 1024 chunk partials per batch row from the stand-alone pass, or one per 16 x 16 output tile of the
     // largest stage from the fused convs, + mean / rstd
@@ -1264,6 +1289,11 @@ struct VaeRun {
     DK_TRY(linear_plain(v->T1, kw, kb, v->Kb, B * T, C, C, DK_EPI_BIAS, st));
     DK_TRY(linear_plain(v->T1, vw, vb, v->Vb, B * T, C, C, DK_EPI_BIAS, st));
     const float scale = 1.0f / sqrtf((float)C);
+    if (g_dk_vae_attn != 0 && C == 512) {
+      // flash form (attention512.hip): no [T, T] score matrix
+      DK_TRY(attention_d512(v->Qb, v->Kb, v->Vb, v->Y, B, T, C, C, scale, v->Vt, st));
+      return linear_call(v->Y, C, B * T, 0, ow, ob, out, C, B * T, 0, B * T, C, C, DK_EPI_RES, nullptr, 0, 0, x, C, B * T, 0, st);
+    }
     for (int b = 0; b < B; ++b) {
       GemmParams g;
       memset(&g, 0, sizeof(g));
@@ -1387,8 +1417,9 @@ static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
   v->Qb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Kb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
-  v->Vt = (bf16_t*)c.take(align_up(tok, 64) * Cm * 2);
-  v->SCORES = (bf16_t*)c.take(tok * align_up(tok, 64) * 2);
+  v->Vt = (bf16_t*)c.take((size_t)B * align_up(tok, 64) * Cm * 2);  // (the flash form transposes every image's V up front)
+  // the materialised score matrix of the general path; a 512-channel mid block runs the flash kernel (attention512.hip) and needs none
+  v->SCORES = (bf16_t*)c.take((Cm == 512 && g_dk_vae_attn != 0) ? 0 : tok * align_up(tok, 64) * 2);
   {
     const size_t tiles = ((size_t)H / 16) * ((size_t)W / 16);
     const size_t npart = tiles > 1024 ? tiles : 1024;

@@ -108,6 +108,20 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], upsample: bool = False
     return y[..., :O]
 
 
+def attention_d512(q: Tensor, k: Tensor, v: Tensor, scale: Optional[float] = None) -> Tensor:
+    """single-head attention over head_dim 512 (VAE mid block, vae.py:28-57), flash-style; q / k / v: [B, T, 512] bf16."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _require_cuda(t, n, BF)
+    B, T, Cc = q.shape
+    out = torch.empty_like(q)
+    vt = torch.empty(B * 512 * lib.dk_attention_d512_tp(T), dtype=BF, device=q.device)
+    scale = scale if scale is not None else 1.0 / math.sqrt(Cc)
+    _lib.check(lib.dk_attention_d512_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, T, Cc, Cc, scale, vt.data_ptr(),
+                                          _stream()), "dk_attention_d512_bf16")
+    return out
+
+
 def groupnorm_table(x: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float, partials: Optional[Tensor] = None,
                     shape=None) -> Tensor:
     """(scale | shift) table [B, 2, C] fp32 of nn.GroupNorm over NHWC ``x`` -- or over the tensor whose output-statistics

@@ -144,6 +144,14 @@ int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, in
 size_t dk_attention_workspace_bytes(void);
 int dk_attention_set_workspace(void* workspace, size_t bytes);
 
+/* Single-head attention over head_dim 512: the VAE mid block's Attention (vae.py:28-57: softmax((q / sqrt 512) k^T) v over all
+ * H * W tokens), flash-style -- the [T, T] score matrix of the reference (537 MB at T = 16384) is never written.  q / k / v / out:
+ * bf16 [B, T, ld] (ld >= 512, multiple of 8); vt_scratch: B * 512 * dk_attention_d512_tp(T) bf16 (the kernel reads a transposed,
+ * zero-padded copy of v that this call writes there first). */
+int32_t dk_attention_d512_tp(int32_t T);
+int dk_attention_d512_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T, int32_t ld, int32_t ldo,
+                           float scale, void* vt_scratch, void* stream);
+
 /* The same with an additive score bias (text encoders): CLIP's causal mask
  * (clip.py:83-89, one [S, ldb] table for every head: bias_head_stride 0) and T5's relative-position
  * bias (t5.py:61-88, [H, S, ldb]); scores = scale * q.k + bias.  ldb: multiple of 64, >= S. */

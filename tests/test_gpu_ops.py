@@ -406,6 +406,32 @@ def test_attention_balanced_form(dev, B, H, S, qfuse):
     assert rel_l2(ref, got) < 6e-3
 
 
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 96), (1, 100), (1, 1000), (2, 4096)])
+def test_attention_d512_flash(dev, B, T):
+    """the VAE mid block's single-head D = 512 attention (vae.py:28-57) on the role-split flash kernel (attention512.hip): ragged
+    query blocks and key tiles, two images, against the oracle's SDPA"""
+    from diffusionkit_amd import ops
+    D = 512
+    q, k, v = (randn(B, T, D, seed=s, scale=sc) for s, sc in ((34, 1.0), (35, 1.0), (36, 1.0)))
+    y = ops.attention_d512(g(q, dev), g(k, dev), g(v, dev))
+    ref = om.sdpa(q[:, None], k[:, None], v[:, None], 1.0 / math.sqrt(D), Prec())[:, 0]
+    assert rel_l2(ref, y.float()) < 6e-3
+    assert max_abs(ref, y.float()) < 0.03
+
+
+def test_attention_d512_spiked_key(dev):
+    """a key that dominates late forces the deferred rescale across the S -> PV hand-off (guide rule 26); fp64 reference"""
+    from diffusionkit_amd import ops
+    T, D = 320, 512
+    q, k, v = (randn(1, T, D, seed=s, scale=0.5) for s in (37, 38, 39))
+    k[0, 250] = bf16r(q[0, 7] * 6.0)  # key 250 aligned with query 7
+    p = torch.softmax(q[0].double() @ k[0].double().t() / math.sqrt(D), dim=-1)
+    ref = (p @ v[0].double())[None]
+    assert float(p[7, 250]) > 0.9
+    y = ops.attention_d512(g(q, dev), g(k, dev), g(v, dev))
+    assert rel_l2(ref, y.float()) < 6e-3
+
+
 def test_attention_spiked_key_forces_rescale(dev):
     """A key that dominates late in the sequence forces the online-softmax rescale path
     (guide rule 26); fp64 reference."""
