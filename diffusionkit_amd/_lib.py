@@ -180,7 +180,7 @@ def load() -> C.CDLL:
             raise DkHipError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dk_abi_version() != 2:
+    if lib.dk_abi_version() != 3:
         raise DkHipError("libdk_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 2
+#define DK_ABI_VERSION 3
 
 int dk_abi_version(void);
 const char* dk_last_error(void);
