@@ -42,12 +42,15 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
     case 7:  // software-pipelined kernel (attention3.hip); D = 64 has no such form: the lean kernel
       rc = p.D == 128 ? dk_launch_attention3(p, 8, stream) : dk_launch_attention2(p, 4, stream);
       break;
-    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 7: pipelined kernel)");
+    case 9:  // phase-alternating kernel (attention4.hip); D = 128 only
+      rc = p.D == 128 ? dk_launch_attention4(p, stream) : dk_launch_attention2(p, 4, stream);
+      break;
+    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 7: pipelined kernel, 9: phase-alternating kernel)");
   }
   dk_prof_end(stream);
   if (rc) return rc;
   DK_CHECK_HIP(hipGetLastError());
-  if (p.O8 != nullptr && !(mode == 7 && p.D == 128)) {
+  if (p.O8 != nullptr && !((mode == 7 || mode == 9) && p.D == 128)) {
     // only the pipelined kernel writes the MX-fp8 copy itself: quantise the bf16 output behind the others
     Mx8Out o8{p.O8, p.O8_scales, p.o8_ld, p.o8_nblk, 0, p.B * p.S, 0, 0};
     return dk_launch_quantize_mx8(p.O, p.ldo, p.B * p.S, 0, p.B * p.S, p.H * p.D, o8, stream);

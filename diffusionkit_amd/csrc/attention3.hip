@@ -29,6 +29,11 @@
 #include "dk_kernels.h"
 
 #define DK3_RESCALE_THR 4.0f  // natural-log units of the scaled scores
+// lab only (scripts/build_attn_abl.sh): parts of the tile body taken out to see what each costs; results are garbage then.
+// 1 softmax VALU, 2 barriers, 4 global loads + LDS stores, 8 K / Q fragment reads, 16 V reads, 32 MFMAs
+#ifndef DK3_ABL
+#define DK3_ABL 0
+#endif
 extern int g_dk_attn_balance;
 #define DK3_SLOT_BYTES (8 * 17 * 1024)  // one partial state: 8 waves x (16 chunks of O + 1 chunk of (m, l)) x 64 lanes x 16 B
 
@@ -213,11 +218,12 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
 // S^T of one tile from K slot SLOT into two independent 32-key accumulators
 #define DK3_QK(SLOT, A0, A1)                                                                                                                   \
   _Pragma("unroll") for (int kk = 0; kk < D / 16; ++kk) {                                                                                      \
-    const bf16x8 k0_ = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + (kr_base ^ (unsigned)(kk << 5)));    \
-    const bf16x8 k1_ = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + 32 * C::ROWB + (kr_base ^ (unsigned)(kk << 5)));  \
-    const bf16x8 q_ = C::QLDS ? *(const __attribute__((address_space(3))) bf16x8*)(lds + q_lds + kk * 1024) : qf[kk];                           \
+    const bf16x8 k0_ = (DK3_ABL & 8) ? abl_f[kk & 1] : *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + (kr_base ^ (unsigned)(kk << 5)));    \
+    const bf16x8 k1_ = (DK3_ABL & 8) ? abl_f[2 + (kk & 1)] : *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + 32 * C::ROWB + (kr_base ^ (unsigned)(kk << 5)));  \
+    const bf16x8 q_ = (DK3_ABL & 8) ? abl_f[kk & 3] : C::QLDS ? *(const __attribute__((address_space(3))) bf16x8*)(lds + q_lds + kk * 1024) : qf[kk];                           \
+    if (DK3_ABL & 32) { asm volatile("" ::"v"(k0_), "v"(k1_), "v"(q_)); } else {                                                                \
     A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0_, q_, A0, 0, 0, 0);                                                                        \
-    A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1_, q_, A1, 0, 0, 0);                                                                        \
+    A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1_, q_, A1, 0, 0, 0); }                                                                      \
   }
 // scores of keys beyond the sequence end (tail tile JT) -> -1e30
 #define DK3_MASK(JT, A0, A1)                                              \
@@ -228,13 +234,14 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   }
 #define DK3_ROWMAX(A0, A1, OUT)                                                                          \
   do {                                                                                                   \
+    if (DK3_ABL & 1) { OUT = m_run; break; }                                                             \
     float m_ = fmaxf(A0[0], A1[0]);                                                                      \
     _Pragma("unroll") for (int e = 1; e < 16; ++e) m_ = fmaxf(m_, fmaxf(A0[e], A1[e]));                  \
     OUT = fmaxf(m_, __shfl_xor(m_, 32, 64));                                                             \
   } while (0)
 // the rare rescale: every accumulator still at the old maximum (O, l) exactly once; nothing else is pending
 #define DK3_RESCALE(MLOC)                                                                                                  \
-  if (!__all((MLOC) - m_run <= thr)) {                                                                                     \
+  if (!(DK3_ABL & 1) && !__all((MLOC) - m_run <= thr)) {                                                                                     \
     const float m_new_ = fmaxf(m_run, (MLOC));                                                                             \
     const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);                                                     \
     m_run = m_new_;                                                                                                        \
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   {                                                                                                           \
     const float mc_ = m_run * c;                                                                              \
     float psum_ = 0.f;                                                                                        \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
+    if (!(DK3_ABL & 1)) _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                      \
       A0[e] = __builtin_amdgcn_exp2f(A0[e] * c - mc_);                                                        \
       A1[e] = __builtin_amdgcn_exp2f(A1[e] * c - mc_);                                                        \
       psum_ += A0[e] + A1[e];                                                                                 \
@@ -260,9 +267,12 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
 #define DK3_PV(SLOT)                                                                                                                        \
   _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) _Pragma("unroll") for (int dt = 0; dt < D / 32; ++dt) { \
     const int imm_ = V_OFF + (SLOT) * C::TILE_BYTES + dt * 4096 + (32 * u + 16 * tt) * 32;                                                  \
+    bf16x8 vf_;                                                                                                                             \
+    if (DK3_ABL & 16) vf_ = abl_f[dt & 3]; else {                                                                                           \
     const s16x4 vh0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm_ + vr_off[dt & 1]));    \
     const s16x4 vh1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm_ + 256 + vr_off[dt & 1])); \
-    const bf16x8 vf_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vh0_, vh1_, 0, 1, 2, 3, 4, 5, 6, 7));                             \
+    vf_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vh0_, vh1_, 0, 1, 2, 3, 4, 5, 6, 7)); }                                        \
+    if (DK3_ABL & 32) { asm volatile("" ::"v"(vf_), "v"(pf[2 * u + tt])); } else                                                           \
     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_, pf[2 * u + tt], o[dt], 0, 0, 0);                                                   \
   }
 #define DK3_ZERO(A0, A1) _Pragma("unroll") for (int e = 0; e < 16; ++e) { A0[e] = 0.f; A1[e] = 0.f; }
@@ -278,6 +288,11 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   bf16x8 pf[4];
   f32x16 sa0, sa1, sb0, sb1;  // scores of the tile being exponentiated / of the tile after it (the roles alternate per tile)
 
+  bf16x8 abl_f[4];  // (lab builds: loop-invariant fragments in place of LDS reads)
+  if (DK3_ABL & 24) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abl_f[i] = qf[i];
+  }
   // ---- prologue: K(0), V(0), K(1) staged; S(0) and its row maximum ----
   load_op(rK, kreg, jb, (jb + 1) * 64 <= S);
   load_op(rV, vreg, jb, (jb + 1) * 64 <= S);
@@ -305,7 +320,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
   {                                                                                                            \
     const int j_ = (J);                                                                                        \
     bool have_k2_ = false, have_v1_ = false;                                                                   \
-    if ((LOADS) == 1) {                                                                                        \
+    if ((LOADS) != 0 && (DK3_ABL & 4)) {                                                                       \
+    } else if ((LOADS) == 1) {                                                                                 \
       load_op(rK, kreg, jb + j_ + 2, true);                                                                    \
       load_op(rV, vreg, jb + j_ + 1, true);                                                                    \
       have_k2_ = have_v1_ = true;                                                                              \
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
     if (have_k2_) { DK3_STORE_K(PAR) }                                                                         \
     if (have_v1_) { DK3_STORE_V((PAR) ^ 1) }                                                                   \
     if (HAVE_N) { DK3_RESCALE(mloc_) }                                                                         \
-    __syncthreads();                                                                                           \
+    if (!(DK3_ABL & 2)) __syncthreads();                                                                       \
   }
 
   // steady state: tiles j with j + 2 full tiles behind them (K(j+2) and V(j+1) complete tiles); two tiles per trip so that the

@@ -162,6 +162,7 @@ extern int g_dk_attn_balance;
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream);  // attention3.hip (two tiles in flight per wave; no score bias)
+int dk_launch_attention4(const AttnParams& p, hipStream_t stream);             // attention4.hip (the waves of a SIMD in opposite phases; D = 128, no score bias)
 
 // ---- single-head D = 512 attention of the VAE's mid block (attention512.hip) -------------------------------
 struct Attn512Params {

@@ -11,7 +11,7 @@ from diffusionkit_amd import ops
 dev = torch.device("cuda", 0)
 shapes = [("flux B1 S4352 D128", 1, 24, 4352, 128), ("flux-dev B1 S4608 D128", 1, 24, 4608, 128), ("sd3 B2 S4685 D64", 2, 24, 4096 + 589, 64),
           ("flux B4", 4, 24, 4352, 128)]
-modes = sys.argv[1:] or ["7", "7b", "4"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
+modes = sys.argv[1:] or ["7", "9", "4"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
 ws = ops.attention_workspace(dev)
 if os.environ.get("ATTN_SHAPES"):
     shapes = shapes[:int(os.environ["ATTN_SHAPES"])]

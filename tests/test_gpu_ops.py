@@ -351,12 +351,13 @@ def test_attention(dev, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
-@pytest.mark.parametrize("mode", [4, 7])
-@pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 3, 1088, 128),
+@pytest.mark.parametrize("mode", [4, 7, 9])
+@pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 2, 129, 128), (1, 2, 192, 128), (1, 2, 250, 128), (1, 3, 1088, 128),
                                      (2, 2, 589 + 64, 64)])
 def test_attention_kernel_variants(dev, mode, B, H, S, D):
-    """Both attention kernels behind dk_tune_set("attn", mode) (4: the VALU-lean kernel with the deferred rescale, 7: the
-    software-pipelined kernel, D = 128; for D = 64 mode 7 falls back to the lean kernel) against the oracle; ragged tail tile."""
+    """The attention kernels behind dk_tune_set("attn", mode) (4: the VALU-lean kernel with the deferred rescale, 7: the
+    software-pipelined kernel, 9: the phase-alternating kernel, both D = 128; for D = 64 they fall back to the lean kernel) against
+    the oracle; ragged tail tile, one to 17 key tiles (the phase-alternating kernel's two wave groups stage different tiles)."""
     from diffusionkit_amd import ops
     h = H * D
     qkv = randn(B, S, 3 * h, seed=32)
@@ -444,7 +445,7 @@ def test_attention_spiked_key_forces_rescale(dev):
     p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
     ref = (p @ v[0])[None]
     assert float(p[7, 250]) > 0.9
-    for mode in (4, 7):  # the deferred-rescale kernels (threshold path; 7: pipelined kernel)
+    for mode in (4, 7, 9):  # the deferred-rescale kernels (threshold path; 7: pipelined, 9: phase-alternating kernel)
         try:
             ops.tune("attn", mode)
             y = ops.attention(g(qkv, dev), H, D)
