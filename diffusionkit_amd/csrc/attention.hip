@@ -8,12 +8,14 @@
 // Layout: q/k/v are read in place from the token-major projection output (row stride ld, head h at column h*D), the output is
 // written token-major so the o-projection GEMM consumes it directly -- no [B,H,S,D] transposes exist anywhere.
 //
-// Kernels: attention2.hip (VALU-lean, deferred rescale, 4 waves of 32 queries; the only one with a score bias) and attention3.hip
-// (two key tiles in flight per wave, 8 waves, D = 128).  Round 3 pruned the variants whose A/B is settled (profiles/r01_attention_lab.md,
+// Kernels: attention2.hip (VALU-lean, deferred rescale, 4 waves of 32 queries; the only one with a score bias), attention3.hip
+// (two key tiles in flight per wave, 8 waves, D = 128; also the balanced stream-K-like launch) and attention4.hip (round 3: the two
+// waves of a SIMD in opposite matrix / vector phases; D = 128; the default on long sequences: +12 % over attention3 on the FLUX
+// shapes in isolation, 815 -> 932 TF inside the model).  Round 3 pruned the variants whose A/B is settled (profiles/r01_attention_lab.md,
 // r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
 #include "dk_kernels.h"
 
-extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3 (8 waves, D = 128 only)
+extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only)
 
 // Hand-off workspace of the balanced form of dk_attn3_fwd_kernel for the launches this host thread enqueues (an engine call sets
 // it to its own engine's region, dk_attention_set_workspace to a caller's buffer; null = plain grids only)
@@ -30,11 +32,12 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   DK_REQUIRE(p.D == 128 || p.D == 64, "head_dim must be 64 or 128");
   DK_REQUIRE(p.S > 0 && p.B > 0 && p.H > 0, "empty attention");
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");
-  // automatic choice (kernel lab, profiles/r01_attention_lab.md, profiles/r02_attn_bench.log): D = 128 on long sequences: the
-  // software-pipelined kernel with 8 waves per workgroup (K/V staging shared by 8 waves; +4 % over the lean kernel on the FLUX
-  // shapes); otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF against 773 / 823 for the pipelined forms).
-  // A score bias (text encoders) is only implemented by the lean kernel's 4-wave form
-  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 7 : 4) : g_dk_attn_mode;
+  // automatic choice (kernel lab, profiles/r01_attention_lab.md, r02_attn_bench.log, r03_attention_phase_alternating.md): D = 128 on
+  // long sequences: the phase-alternating kernel (8 waves per workgroup; 1018 / 1053 / 1078 TF against 908 / 961 / 978 for the
+  // pipelined kernel on FLUX B1 / FLUX-dev B1 / FLUX B4, same box); otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF
+  // against 773 / 823 for the pipelined forms).  A score bias (text encoders) is only implemented by the lean kernel's 4-wave form;
+  // the balanced launch (dk_tune_set("attn_balance", 1)) belongs to the pipelined kernel: it needs "attn" = 7 as well
+  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 9 : 4) : g_dk_attn_mode;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   int rc = 0;
   switch (mode) {

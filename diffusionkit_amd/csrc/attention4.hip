@@ -4,19 +4,25 @@
 // python/src/diffusionkit/mlx/mmdit.py:562,643,687,736): transposed scores S^T = K Q^T on v_mfma_f32_32x32x16_bf16, lane-local
 // online softmax with the deferred rescale (threshold 4), O^T += V^T P^T with V through ds_read_b64_tr_b16.
 //
-// Why (round 3 measurements, profiles/r03_issue_probe.log, r03_attention_ablations.log): the instruction MIX of this algorithm --
-// per MFMA five VALU, one exponential, 1.5 LDS fragment reads -- runs at 79 % of the bare MFMA rate when it is issued in a fixed
-// interleaved order by independent waves; the pipelined kernel reaches 40 %.  Its ablation builds say the matrix pipe alone needs
-// 52 % of the launch and everything else alone 64 %: the two barely overlap, because both waves of a SIMD run the same part of the
-// same tile at the same time (the per-tile barrier re-aligns them), and a wave that carries two tiles in flight has no registers
-// left to read its fragments ahead (256 VGPRs, 14 spilled).
+// Why (round 3 measurements; profiles/r03_attention_phase_alternating.md): the pipelined kernel's ablation builds say the matrix pipe
+// alone needs 52 % of the launch and everything else alone 64 %: the two barely overlap, because both waves of a SIMD run the same
+// part of the same tile at the same time (the per-tile barrier re-aligns them), and a wave that carries two tiles in flight has no
+// registers left to read its fragments ahead (256 VGPRs, 14 spilled).
 //
 // Here the two waves of a SIMD are kept in OPPOSITE phases by construction.  A tile is two phases per wave:
-//   M phase (matrix pipe):  O += V(j-1) P(j-1), then S(j) = K(j) Q^T     32 MFMAs + 48 fragment reads, no VALU to speak of
+//   M phase (matrix pipe):  O += V(j-1) P(j-1), then S(j) = K(j) Q^T: 32 MFMAs and
+//                           48 fragment reads through a ring of 8 register slots, each read issued 7 MFMAs before its use
 //   V phase (vector ALU):   row maximum, rescale vote, P(j) = exp2(...), row sums, bf16 packing; LDS stores of the staged K / V
 // and every phase ends at the workgroup barrier.  Waves 0-3 (group A) start with M(0); waves 4-7 (group B: wave w + 4 shares its
 // SIMD with wave w) pass one extra barrier first, so that B runs M(j) while A runs V(j), and A runs M(j+1) while B runs V(j).  One
-// score tile in flight per wave: 64 (O) + 32 (S) + 16 (P) + 32 (Q) + 16 (staging) registers leave ~90 for fragments read ahead.
+// score tile in flight per wave: 64 (O) + 32 (S) + 16 (P) + 32 (Q) + 16 (staging) + 32 (ring) registers, no spills.
+//
+// What bounds it (same file of measurements): one wave issues a VALU instruction every ~5 cycles and an exponential every ~12, so
+// the V phase of a lone wave (33 exponentials + ~115 other VALU instructions) is as long as the M phase (32 MFMAs x 32 cycles), and
+// VALU results complete hundreds of cycles behind the wave's scalar stream: whichever phase first touches P pays for the tail of
+// the V phase in front of it (the s_memtime traces show it as a slow P.V in every other tile).  Tried on top and measured flat or
+// worse: three LDS slots with the first fragments of an M phase read before its barrier, one barrier per tile, the scores ahead
+// of P.V inside the M phase, the row sums through the matrix pipe (4 more MFMAs per tile for 32 fewer v_add), wave priorities.
 //
 // K / V staging through two LDS slots each; with the groups one period apart the rule "a slot is rewritten after its last reader
 // and before its next" gives: in V(j) group A stores K(j+1) and V(j), group B stores K(j+2) and V(j+1) (B's threads hold the tile
@@ -24,13 +30,14 @@
 #include "dk_kernels.h"
 
 #define DK4_RESCALE_THR 4.0f  // natural-log units of the scaled scores
-#ifndef DK4_PRIO
-#define DK4_PRIO 0  // lab: 1 = raise the wave priority through the M phase
-#endif
-// lab only (scripts/build_attn_abl.sh): parts of a tile taken out to see what each costs; results are garbage then.
-// 1 softmax VALU, 4 global loads + LDS stores, 32 MFMAs (the fragment reads stay)
+// lab only (scripts/build_attn_abl.sh, K=4): parts of a tile taken out to see what each costs; results are garbage then.
+// 1 softmax VALU, 4 global loads + LDS stores, 32 MFMAs (the fragment reads stay), 64 V fragment reads, 128 K fragment reads
 #ifndef DK4_ABL
 #define DK4_ABL 0
+#endif
+// lab only (scripts/attn_trace.py): waves 0 and 4 of workgroup 0 stamp s_memtime at the phase boundaries of tiles 20..27 into p.bal_ws
+#ifndef DK4_TRACE
+#define DK4_TRACE 0
 #endif
 
 struct Attn4Cfg {
@@ -48,12 +55,12 @@ struct Attn4Cfg {
 
 typedef __attribute__((address_space(3))) char lds_char4;
 
-// the value the lane 32 away holds (v_permlane32_swap: one VALU instruction; __shfl_xor(x, 32) is a ds_bpermute round trip
-// through the LDS pipe, whose latency sits on the V phase's critical path)
-__device__ __forceinline__ float dk4_other_half(float x) {
+// max of a value over a lane and the lane 32 away (v_permlane32_swap: one VALU instruction; __shfl_xor(x, 32) is a ds_bpermute
+// round trip through the LDS pipe)
+__device__ __forceinline__ float dk4_max_halves(float x) {
   const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(threadIdx.x & 32 ? r[0] : r[1]);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0]: the lower half's value in both halves, r[1]: the upper half's
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 template <bool QFUSE>
@@ -192,7 +199,9 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 // right behind MFMA i, 7 MFMAs (224 matrix-pipe cycles) before it is needed, and sched_barriers pin that order -- left to itself
 // hipcc reads each fragment directly in front of its MFMA and waits out the LDS latency 32 times per tile.
 #define DK4_R1(I, SLOT)                                                                                                                        \
-  if ((I) < 16) {                                                                                                                              \
+  if (((I) < 16 && (DK4_ABL & 64)) || ((I) >= 16 && (DK4_ABL & 128))) {                                                                        \
+    asm volatile("" : "+v"(fr[(I) & 7]));                                                                                                      \
+  } else if ((I) < 16) {                                                                                                                              \
     const int dt_ = (I) & 3, n_ = (I) >> 2;                                                                                                    \
     const int imm_ = V_OFF + ((SLOT) ^ 1) * C::TILE_BYTES + dt_ * 4096 + (32 * (n_ >> 1) + 16 * (n_ & 1)) * 32;                                \
     const s16x4 vh0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm_ + vr_off[dt_ & 1]));       \
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 #define DK4_M1(I)                                                                                                     \
   if (DK4_ABL & 32) {                                                                                                 \
     asm volatile("" ::"v"(fr[(I) & 7]));                                                                              \
-  } else if ((I) < 16) {                                                                                                     \
+  } else if ((I) < 16) {                                                                                              \
     o[(I) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(I) & 7], pf[((I) >> 2) & 3], o[(I) & 3], 0, 0, 0);       \
   } else if ((I) & 1) { /* (the first step of a score chain accumulates onto the inline constant 0: no 32 v_mov per tile) */ \
     s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(I) & 7], qf[(((I) - 16) >> 1) & 7], (I) == 17 ? zero16 : s1, 0, 0, 0); \
@@ -243,6 +252,8 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;  // p = 2^(s*c - m*c)
   const float thr = DK4_RESCALE_THR / p.scale;         // threshold on the raw scores
+  const bool trace_on = DK4_TRACE && blockIdx.x == 0 && (wave & 3) == 0 && p.bal_ws != nullptr;
+  unsigned long long* const trace_buf = (unsigned long long*)p.bal_ws + (wave >> 2) * 64;  // 8 tiles x 6 stamps per group
   bf16x8 pf[4];
   f32x16 s0, s1;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -269,10 +280,17 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 
   // One tile: M phase, barrier, V phase, barrier.  PAR = J & 1 (compile-time: LDS slots as immediates).
   // LOADS: 1 = this group's K(J + 1 + grp) and V(J + grp) are complete tiles (steady state: no checks), 2 = generic
+#define DK4_STAMP(J, K)                                                                   \
+  if (DK4_TRACE && trace_on && (J) >= 20 && (J) < 28) {                                   \
+    unsigned long long t_;                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    if (lane == 0) trace_buf[((J) - 20) * 6 + (K)] = t_;                                  \
+  }
 #define DK4_STEP(J, PAR, LOADS, FIRST)                                                                              \
   {                                                                                                            \
     const int j_ = (J);                                                                                        \
     const int kt_ = j_ + 1 + grp, vt_ = j_ + grp;                                                              \
+    DK4_STAMP(j_, 0)                                                                                           \
     bool have_k_ = true, have_v_ = true;                                                                       \
     if (DK4_ABL & 4) {                                                                                         \
       have_k_ = have_v_ = false;                                                                               \
@@ -286,10 +304,17 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
       if (have_v_) load_op(rV, vreg, vt_, (vt_ + 1) * 64 <= S);                                                \
     }                                                                                                          \
     /* ---- M phase ---- */                                                                                    \
-    if (DK4_PRIO) __builtin_amdgcn_s_setprio(2);                                                               \
-    DK4_MSEQ(PAR, FIRST, 32)                                                                                   \
-    if (DK4_PRIO) __builtin_amdgcn_s_setprio(0);                                                               \
+    DK4_STAMP(j_, 1)                                                                                           \
+    if (DK4_TRACE && (FIRST) == 0) {                                                                           \
+      DK4_MSEQ(PAR, 0, 16)                                                                                     \
+      DK4_STAMP(j_, 2)                                                                                         \
+      DK4_MSEQ(PAR, 16, 32)                                                                                    \
+    } else {                                                                                                   \
+      DK4_MSEQ(PAR, FIRST, 32)                                                                                 \
+    }                                                                                                          \
+    DK4_STAMP(j_, 3)                                                                                           \
     DK4_PHASE_END                                                                                              \
+    DK4_STAMP(j_, 4)                                                                                           \
     /* ---- V phase ---- */                                                                                    \
     if ((LOADS) != 1) {                                                                                        \
       if ((j_ + 1) * 64 > S) { DK4_MASK(j_, s0, s1) }                                                          \
@@ -297,9 +322,10 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
     {                                                                                                          \
       float mx_ = fmaxf(s0[0], s1[0]);                                                                         \
       if (!(DK4_ABL & 1)) {                                                                                    \
-      _Pragma("unroll") for (int e = 1; e < 16; ++e) mx_ = fmaxf(mx_, fmaxf(s0[e], s1[e]));                    \
-      mx_ = fmaxf(mx_, dk4_other_half(mx_)); }                                                                 \
-      if (!(DK4_ABL & 1) && !__all(mx_ - m_run <= thr)) {                                                                        \
+        _Pragma("unroll") for (int e = 1; e < 16; ++e) mx_ = __builtin_fmaxf(__builtin_fmaxf(mx_, s0[e]), s1[e]); /* v_max3 */ \
+        mx_ = dk4_max_halves(mx_);                                                                             \
+      }                                                                                                        \
+      if (!(DK4_ABL & 1) && !__all(mx_ - m_run <= thr)) {                                                      \
         const float m_new_ = fmaxf(m_run, mx_);                                                                \
         const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);                                     \
         m_run = m_new_;                                                                                        \
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
     }                                                                                                          \
     if (have_k_) { DK4_STORE_K(PAR) }                                                                          \
     if (have_v_) { DK4_STORE_V(PAR) }                                                                          \
+    DK4_STAMP(j_, 5)                                                                                           \
     DK4_PHASE_END                                                                                              \
   }
 
@@ -348,8 +375,7 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   if (grp == 0) __syncthreads();
 
   // ---- normalise and store: lane owns query q0+l31, d = dt*32 + 8g + 4hi + {0..3} ----
-  const float lsum = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / lsum;
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
   const int q = q0 + l31;
   if (p.O8 != nullptr) {
     // MX-fp8 output: a 32-column block (one dt) of a query row lives in this lane and lane ^ 32 (16 values each)
@@ -392,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
       }
   }
 #undef DK4_STEP
+#undef DK4_STAMP
 #undef DK4_STORE_K
 #undef DK4_STORE_V
 #undef DK4_R1

@@ -331,6 +331,39 @@ def test_fused_key_norm_matches_separate_pass(dev, B, mf, side):
     assert float(d.max()) <= 0.05 * float(outs[0].abs().max())
 
 
+@pytest.mark.parametrize("B,side", [(1, 128), (2, 104)])
+def test_attention_kernels_agree_inside_the_model(dev, B, side):
+    """The three attention kernels behind dk_tune_set("attn", ...) inside a FLUX double + single block pair, with the queries'
+    QKNorm + RoPE fused into the kernel's Q load (default) and as a separate pass: 9 = phase-alternating kernel (the default at these
+    lengths), 7 = pipelined kernel, 4 = lean kernel.  Latent side 104: S = 2960, ragged last key tile and last query block, two
+    images.  7 and 9 share their arithmetic (same order of every sum): identical outputs; the lean kernel's tiles are the same too."""
+    from dataclasses import replace
+    from diffusionkit_amd import ops
+    cfg = replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1)
+    eng, _ = build(cfg, dev)
+    text = randn(B, 256, cfg.token_level_text_embed_dim, seed=3)
+    pooled = randn(B, cfg.pooled_text_embed_dim, seed=4)
+    lat = randn(B, side, side, 16, seed=5)
+    eng.prepare(B, (side, side), 256, 2)
+    eng.cache_modulation_params(pooled.to(dev), [1000.0, 752.0])
+    tok = eng.patchify(lat.to(dev))
+    outs = {}
+    try:
+        for fq in (1, 0):
+            ops.tune("attn_fuse_q", fq)
+            for mode in (9, 7, 4):
+                ops.tune("attn", mode)
+                outs[(mode, fq)] = eng.forward_tokens(tok, text.to(dev, BF), 1).float().cpu()
+    finally:
+        ops.tune("attn", -1)
+        ops.tune("attn_fuse_q", -1)
+    ref = outs[(7, 1)]
+    assert torch.isfinite(ref).all()
+    assert torch.equal(outs[(9, 1)], ref) and torch.equal(outs[(9, 0)], outs[(7, 0)])
+    for key, o in outs.items():
+        assert rel_l2(ref, o) < 4e-3, (key, float(rel_l2(ref, o)))
+
+
 def test_sd3_width_cfg_batch(dev):
     """SD3-medium geometry (h 1536, 24 heads, D 64, learned pos-emb, conv patchify), CFG batch 2,
     latent 64x64 (BASELINE config #1 size), S_t = 154, depth 2."""
