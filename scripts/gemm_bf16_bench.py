@@ -37,5 +37,12 @@ for name, M, N, K in shapes:
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 24)
-    out.append(f"{name} {M}x{N}x{K}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF")
+    chk = ""
+    if os.environ.get("CHECK"):
+        ref = x[:512].float() @ w.float().t()
+        ops.linear(x, w, b, out=y, epilogue=epi)
+        got = y[:512].float()
+        if epi == ops.DK_EPI_BIAS:
+            chk = f" relL2 {float((got - ref).norm() / ref.norm()):.1e}"
+    out.append(f"{name} {M}x{N}x{K}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF{chk}")
 print(os.environ.get("DK_HIP_LIB", "default lib"), "MF=" + os.environ.get("MF", "auto"), "EPI=" + os.environ.get("EPI", "bias"), "COLD_W=" + os.environ.get("COLD_W", "1"), " | ".join(out), flush=True)
