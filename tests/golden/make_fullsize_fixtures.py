@@ -87,6 +87,13 @@ FLUX_BLOCKS = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=256, ti
                    x_seed=31, rows=tuple(list(range(0, 16)) + list(range(240, 272)) + list(range(2296, 2312)) + list(range(4336, 4352))))
 
 
+# one double + one single block at width (every launch shape of the bench, bf16 and fp8): the oracle outputs the two "width block
+# pair" GPU tests compare against -- the fp32 and bf16-emulating oracles, and both again on the fake-quantised weights / activations
+# of the fp8 path (oracle/fp8.py); every 4th image token is kept
+FLUX_PAIR = dict(cfg=replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1), seed_w=1234, B=1, latent=(128, 128), S_t=256,
+                 timesteps=[1000.0, 752.0], step=1, row_stride=4)
+
+
 def ref_model(cfg, w, P):
     """the oracle with the reference's config-dtype timestep embedding (quirk Q2) whatever the activation precision ``P``"""
     return OracleMMDiT(cfg, w, P, embed_prec=Prec(embed_dtype(cfg)))
@@ -289,7 +296,29 @@ def make_flux_blocks():
     return out
 
 
-CASES = {"sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
+def make_flux_pair():
+    from oracle import fp8 as o8
+    c = FLUX_PAIR
+    cfg = c["cfg"]
+    named = synth_mmdit_weights(cfg, seed=c["seed_w"])
+    plain = {k: v.float() for k, v in named.items()}
+    fq = o8.fake_quant_block_weights(replace(cfg, weight_dtype="fp8_e4m3"), named)
+    text, pooled, lat = forward_inputs(c)
+    ts = c["timesteps"]
+    out = {}
+    for name, w, P, aq in (("fp32", plain, Prec(), None), ("emu", plain, Prec(BF), None), ("fq_fp32", fq, Prec(), o8.mx8_fake_quant),
+                           ("fq_emu", fq, Prec(BF), o8.mx8_fake_quant)):
+        t0 = time.time()
+        m = OracleMMDiT(replace(cfg, weight_dtype="fp8_e4m3") if aq is not None else cfg, w, P, act_quant=aq, embed_prec=Prec(embed_dtype(cfg)))
+        m.cache_modulation_params(pooled, torch.tensor(ts))
+        taps = {}
+        m(lat, text, ts[c["step"]], taps=taps)
+        out["final_" + name] = taps["final"][:, ::c["row_stride"]].contiguous().numpy()
+        print(f"flux_pair {name}: {time.time() - t0:.0f} s", flush=True)
+    return out
+
+
+CASES = {"flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
          "flux_1024": lambda: make_forward(FLUX_1024, "flux_1024"), "flux_full": make_flux_full,
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,

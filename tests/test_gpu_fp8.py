@@ -170,8 +170,8 @@ def test_mmdit_fp8_rejects_unaligned_token_counts(dev):
 def test_flux_width_block_pair_fp8(dev):
     """FLUX geometry (h 3072, 24 heads, S = 256 + 4096), depth 1 + 1, fp8 weights: every fp8 launch at the BASELINE shapes
     (grouped text + image GEMMs, the column-split linear1 with its MX-fp8 second output, K = 15360 linear2)."""
-    cfg = replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1, weight_dtype="fp8_e4m3")
-    out, res = _fp8_forward_case(cfg, dev, 1, 128, 128, 256, [1000.0, 752.0], 1)
+    from tests.test_gpu_model import flux_pair_case
+    out, res = flux_pair_case(dev, fp8=True)
     e_h, e_e = rel_l2(res["fq_fp32"], out), rel_l2(res["fq_fp32"], res["fq_emu"])
     print(f"fp8 flux width: hip-vs-fq {e_h:.3e}, emu-vs-fq {e_e:.3e}; PSNR vs un-quantised fp32 {psnr(res['fp32'], out):.1f} dB "
           f"(fake-quant oracle {psnr(res['fp32'], res['fq_fp32']):.1f} dB)")

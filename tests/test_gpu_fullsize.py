@@ -63,13 +63,71 @@ def check(name, ref, got, f=None, emu_keys=("emu_psnr", "emu_rel_l2")):
         assert e <= max_e, f"{name}: rel-L2 {e:.3e} > {max_e}"
 
 
+# ---- seeded weight sets, drawn ahead of the tests that use them -----------------------------------------------------------------
+# The weights of a case come out of ONE sequential CPU generator stream (the fixture generator drew them the same way), 40-300 M
+# values per second: 60 s for the 12 B parameters of FLUX.1-schnell, 10 s for SD3-medium.  Background threads draw the sets while
+# earlier tests run on the GPU (torch.randn releases the GIL); a test takes its set from there, or draws it itself when no thread
+# is running (a selection with -k).
+import threading  # noqa: E402
+
+_SYNTH_PLAN = []   # (key, cfg, seed, uses) in file order
+_SYNTH = {}        # key -> [weights, uses left]
+_SYNTH_COND = threading.Condition()
+_SYNTH_THREAD = []
+
+
+def _synth_key(cfg, seed):
+    from dataclasses import replace
+    return (repr(replace(cfg, weight_dtype="bf16")) if hasattr(cfg, "weight_dtype") else repr(cfg), int(seed))
+
+
+def _synth_worker(plan):
+    for key, cfg, seed, uses in plan:
+        w = synth_mmdit_weights(cfg, seed=seed)
+        with _SYNTH_COND:
+            _SYNTH[key] = [w, uses]
+            _SYNTH_COND.notify_all()
+
+
+def start_synth_prefetch():
+    """called by tests/conftest.py at the START of a GPU session that runs this whole file: two threads, the 12 B parameters of
+    FLUX.1-schnell in one, the smaller sets in file order in the other -- they are ready when the earlier test files are through"""
+    if _SYNTH_THREAD:
+        return
+    small = []
+    for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 1)):
+        small.append((_synth_key(c["cfg"], c["seed_w"]), c["cfg"], c["seed_w"], uses))
+    big = [(_synth_key(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"]), fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], 1)]
+    _SYNTH_PLAN.extend(big + small)
+    for plan in (big, small):
+        th = threading.Thread(target=_synth_worker, args=(plan,), daemon=True)
+        _SYNTH_THREAD.append(th)
+        th.start()
+
+
+def synth_cached(cfg, seed, keep=False):
+    """the weight set of (cfg, seed): a private (shallow) copy of the dict, so that pack_mmdit(consume=True) can empty it"""
+    key = _synth_key(cfg, seed)
+    if _SYNTH_THREAD and any(k == key for k, *_ in _SYNTH_PLAN):
+        with _SYNTH_COND:
+            while key not in _SYNTH:
+                _SYNTH_COND.wait(timeout=600)
+            ent = _SYNTH[key]
+            ent[1] -= 1
+            w = ent[0]
+            if ent[1] <= 0 and not keep:
+                del _SYNTH[key]
+        return dict(w)
+    return synth_mmdit_weights(cfg, seed=seed)
+
+
 _FLUX_SYNTH = {}
 
 
 def flux_full_synth():
     """the seeded 57-block FLUX.1-schnell weight set (bf16 on the host, 24 GB), drawn once per test session"""
     if "w" not in _FLUX_SYNTH:
-        _FLUX_SYNTH["w"] = synth_mmdit_weights(fx.FLUX_FULL["cfg"], seed=fx.FLUX_FULL["seed_w"])
+        _FLUX_SYNTH["w"] = synth_cached(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], keep=True)
     return _FLUX_SYNTH["w"]
 
 
@@ -79,7 +137,7 @@ def test_sd3_medium_512_full_depth_pipeline(dev):
     from diffusionkit_amd.pipeline import DiffusionPipeline
     f = load("sd3_512")
     c = fx.SD3_512
-    packed = {"mmdit": pack_mmdit(c["cfg"], synth_mmdit_weights(c["cfg"], seed=c["seed_w"]), dev, consume=True),
+    packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True),
               "vae_decoder": pack_vae(VAEDecoderConfig(), synth_vae_weights(VAEDecoderConfig(), seed=c["seed_vae"]), dev)}
     pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
     text, pooled = fx.sd3_512_inputs()
@@ -111,7 +169,7 @@ def test_vae_decode_1024_vs_oracle(dev):
 def _forward(c, dev):
     from diffusionkit_amd.engine import MMDiTEngine
     cfg = c["cfg"]
-    eng = MMDiTEngine(cfg, pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=c["seed_w"]), dev, consume=True))
+    eng = MMDiTEngine(cfg, pack_mmdit(cfg, synth_cached(cfg, c["seed_w"]), dev, consume=True))
     text, pooled, lat = fx.forward_inputs(c)
     eng.prepare(c["B"], c["latent"], c["S_t"], len(c["timesteps"]))
     eng.cache_modulation_params(pooled.to(dev), c["timesteps"])
@@ -193,7 +251,7 @@ def test_sd3_medium_1024_full_depth_cfg_first_steps(dev):
     from diffusionkit_amd.pipeline import CFGDenoiser, DiffusionPipeline, sample_euler
     f = load("sd3_full_1024")
     c = fx.SD3_FULL_1024
-    packed = {"mmdit": pack_mmdit(c["cfg"], synth_mmdit_weights(c["cfg"], seed=c["seed_w"]), dev, consume=True),
+    packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True),
               "vae_decoder": pack_vae(VAEDecoderConfig(), synth_vae_weights(VAEDecoderConfig(), seed=4321), dev)}
     pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
     text, pooled = fx.sd3_full_inputs()
