@@ -26,7 +26,7 @@
 //
 // K / V staging through two LDS slots each; with the groups one period apart the rule "a slot is rewritten after its last reader
 // and before its next" gives: in V(j) group A stores K(j+1) and V(j), group B stores K(j+2) and V(j+1) (B's threads hold the tile
-// one further ahead); the global loads of what a V phase stores are issued at the top of the M phase before it.
+// one further ahead); a V phase starts with these stores and the global loads of what the NEXT V phase stores.
 #include "dk_kernels.h"
 
 #define DK4_RESCALE_THR 4.0f  // natural-log units of the scaled scores
@@ -277,6 +277,11 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   }
   __syncthreads();
   if (grp == 1) __syncthreads();  // B idles through A's M(0)
+  // the tiles V(0) stores: K(1 + grp), V(grp)
+  if (!(DK4_ABL & 4)) {
+    if (1 + grp < nt) load_op(rK, kreg, 1 + grp, (2 + grp) * 64 <= S);
+    if (grp < nt) load_op(rV, vreg, grp, (1 + grp) * 64 <= S);
+  }
 
   // One tile: M phase, barrier, V phase, barrier.  PAR = J & 1 (compile-time: LDS slots as immediates).
   // LOADS: 1 = this group's K(J + 1 + grp) and V(J + grp) are complete tiles (steady state: no checks), 2 = generic
@@ -289,20 +294,8 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 #define DK4_STEP(J, PAR, LOADS, FIRST)                                                                              \
   {                                                                                                            \
     const int j_ = (J);                                                                                        \
-    const int kt_ = j_ + 1 + grp, vt_ = j_ + grp;                                                              \
+    const int kt_ = j_ + 1 + grp, vt_ = j_ + grp; /* the tiles this V phase stores (in registers since the V phase before) */ \
     DK4_STAMP(j_, 0)                                                                                           \
-    bool have_k_ = true, have_v_ = true;                                                                       \
-    if (DK4_ABL & 4) {                                                                                         \
-      have_k_ = have_v_ = false;                                                                               \
-    } else if ((LOADS) == 1) {                                                                                 \
-      load_op(rK, kreg, kt_, true);                                                                            \
-      load_op(rV, vreg, vt_, true);                                                                            \
-    } else {                                                                                                   \
-      have_k_ = kt_ < nt;                                                                                      \
-      have_v_ = vt_ < nt;                                                                                      \
-      if (have_k_) load_op(rK, kreg, kt_, (kt_ + 1) * 64 <= S);                                                \
-      if (have_v_) load_op(rV, vreg, vt_, (vt_ + 1) * 64 <= S);                                                \
-    }                                                                                                          \
     /* ---- M phase ---- */                                                                                    \
     DK4_STAMP(j_, 1)                                                                                           \
     if (DK4_TRACE && (FIRST) == 0) {                                                                           \
@@ -316,6 +309,22 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
     DK4_PHASE_END                                                                                              \
     DK4_STAMP(j_, 4)                                                                                           \
     /* ---- V phase ---- */                                                                                    \
+    /* staging first: the tiles loaded a tile ago go to their slots (free since the barrier just passed), the loads of the \
+       next ones (one tile further on) are issued: an M phase meets no global memory instruction */            \
+    if (!(DK4_ABL & 4)) {                                                                                      \
+      if ((LOADS) == 1) {                                                                                      \
+        DK4_STORE_K(PAR)                                                                                       \
+        DK4_STORE_V(PAR)                                                                                       \
+        load_op(rK, kreg, kt_ + 1, true);                                                                      \
+        load_op(rV, vreg, vt_ + 1, true);                                                                      \
+      } else {                                                                                                 \
+        if (kt_ < nt) { DK4_STORE_K(PAR) }                                                                     \
+        if (vt_ < nt) { DK4_STORE_V(PAR) }                                                                     \
+        if (kt_ + 1 < nt) load_op(rK, kreg, kt_ + 1, (kt_ + 2) * 64 <= S);                                     \
+        if (vt_ + 1 < nt) load_op(rV, vreg, vt_ + 1, (vt_ + 2) * 64 <= S);                                     \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
     if ((LOADS) != 1) {                                                                                        \
       if ((j_ + 1) * 64 > S) { DK4_MASK(j_, s0, s1) }                                                          \
     }                                                                                                          \
@@ -344,21 +353,19 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
         pf[0][e] = (__bf16)s0[e]; pf[1][e] = (__bf16)s0[8 + e]; pf[2][e] = (__bf16)s1[e]; pf[3][e] = (__bf16)s1[8 + e]; \
       }                                                                                                        \
     }                                                                                                          \
-    if (have_k_) { DK4_STORE_K(PAR) }                                                                          \
-    if (have_v_) { DK4_STORE_V(PAR) }                                                                          \
     DK4_STAMP(j_, 5)                                                                                           \
     DK4_PHASE_END                                                                                              \
   }
 
   const int n_full = S / 64;  // tiles 0 .. n_full - 1 are complete
   // tile 0 has no P.V in front of its scores
-  if (3 < n_full) {
+  if (4 < n_full) {
     DK4_STEP(0, 0, 1, 16)
   } else {
     DK4_STEP(0, 0, 2, 16)
   }
   int j = 1;
-  for (; j + 3 < n_full; j += 2) {  // second body: K(j + 3) for group B must be a complete tile
+  for (; j + 4 < n_full; j += 2) {  // second body: group B loads K(j + 4), which must be a complete tile
     DK4_STEP(j, 1, 1, 0)
     DK4_STEP(j + 1, 0, 1, 0)
   }
