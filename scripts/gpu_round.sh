@@ -31,7 +31,7 @@ if has pmc; then
   # counters in their own runs (kernel-trace only), CSV output; FETCH_SIZE and WRITE_SIZE cannot share a pass
   for CNT in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"; do
     TAGC=$(echo $CNT | cut -d" " -f1)
-    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CNT -d $OLDPWD/$OUT/pmc_$TAGC -o flux --output-format csv -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OLDPWD/$OUT/pmc_$TAGC.log 2>&1)
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CNT -d $OLDPWD/$OUT/pmc_$TAGC -o flux --output-format csv -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-configs > $OLDPWD/$OUT/pmc_$TAGC.log 2>&1)
     echo "pmc $TAGC exit $?"
     find $OUT/pmc_$TAGC -name "*kernel_trace.csv" -size +30M -delete
   done
