@@ -8,7 +8,8 @@ weight broadcast at load, no collectives in the step loop).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Other BASELINE.json lines: --workload sd3-medium-1024 (configs[2]), --workload flux-dev-1024 --fp8 (configs[3]),
---batch 8 on 8 GPUs (configs[4]: 64 images per step over the node).
+--batch 8 on 8 GPUs (configs[4]: 64 images per step over the node; --batch auto picks it when N > 1).  The default single-GPU run
+appends short legs of configs[2] and configs[3] to the same JSON line as "other_configs" (--no-other-configs skips them).
 
 A "step" is one pass of the hot path over one synthetic input per rank: the denoising steps (MMDiT
 forward + fused CFG/Euler update) followed by the VAE latent decode to a uint8 image.  Inputs
