@@ -17,12 +17,14 @@
 // SIMD with wave w) pass one extra barrier first, so that B runs M(j) while A runs V(j), and A runs M(j+1) while B runs V(j).  One
 // score tile in flight per wave: 64 (O) + 32 (S) + 16 (P) + 32 (Q) + 16 (staging) + 32 (ring) registers, no spills.
 //
-// What bounds it (same file of measurements): one wave issues a VALU instruction every ~5 cycles and an exponential every ~12, so
-// the V phase of a lone wave (33 exponentials + ~115 other VALU instructions) is as long as the M phase (32 MFMAs x 32 cycles), and
-// VALU results complete hundreds of cycles behind the wave's scalar stream: whichever phase first touches P pays for the tail of
-// the V phase in front of it (the s_memtime traces show it as a slow P.V in every other tile).  Tried on top and measured flat or
-// worse: three LDS slots with the first fragments of an M phase read before its barrier, one barrier per tile, the scores ahead
-// of P.V inside the M phase, the row sums through the matrix pipe (4 more MFMAs per tile for 32 fewer v_add), wave priorities.
+// What is left (same file of measurements; FLUX shape, 228-230 us): the MFMAs alone take 139 us; with the fragment reads and the
+// two barriers per tile but no softmax arithmetic and no K / V staging 201 us; staging +10, softmax +18 (half of it the
+// exponentials).  The skeleton -- one wave per SIMD feeding the matrix pipe at a time, an LDS latency at the start of every M phase,
+// two workgroup barriers per tile -- is the larger part of the gap; the V phase of a lone wave (33 exponentials at ~12 cycles, ~115
+// other VALU instructions at ~5) is about as long as its M phase.  Tried on top and measured flat or worse: three LDS slots with
+// the first fragments of an M phase read before its barrier, one barrier per tile, the barrier a few MFMAs before the end of the M
+// phase, the scores ahead of P.V, the row sums through the matrix pipe, pre-scaled queries (no multiply-subtract per score), one
+// loop body instead of two, wave priorities.
 //
 // K / V staging through two LDS slots each; with the groups one period apart the rule "a slot is rewritten after its last reader
 // and before its next" gives: in V(j) group A stores K(j+1) and V(j), group B stores K(j+2) and V(j+1) (B's threads hold the tile
