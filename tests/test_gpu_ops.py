@@ -338,7 +338,10 @@ def test_latent_sample(dev):
 
 # ---- attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 128, 128), (1, 3, 200, 128), (2, 4, 333, 64), (1, 24, 1088, 128),
-                                     (2, 24, 589 + 64, 64)])
+                                     (2, 24, 589 + 64, 64),
+                                     # the automatic choice at D = 128, S >= 2048 (phase-alternating kernel): ragged last key tile
+                                     # and last query block, two images; a whole number of both
+                                     (2, 3, 2048 + 17, 128), (1, 2, 2304, 128)])
 def test_attention(dev, B, H, S, D):
     from diffusionkit_amd import ops
     h = H * D
