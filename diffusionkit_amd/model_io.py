@@ -381,11 +381,65 @@ def _check_against(out: StateDict, want, what: str) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# MLX group-quantised checkpoints (the reference's ``*-4bit-quantized`` model versions)
+# ---------------------------------------------------------------------------------------------
+MLX_QUANT_GROUP = 64  # nn.quantize defaults (mlx/model_io.py:731-733,775 call it without arguments)
+MLX_QUANT_BITS = 4
+
+
+def dequantize_mlx(wq: Tensor, scales: Tensor, biases: Tensor, group_size: int = MLX_QUANT_GROUP, bits: int = MLX_QUANT_BITS) -> Tensor:
+    """``mx.dequantize``: uint32 packs [out, in * bits / 32] + per-group scales / biases [out, in / group_size] -> bf16 [out, in];
+    element j of a pack sits in bits [bits * j, bits * (j + 1)), w = scale * q + bias evaluated in fp32 (oracle/mlxquant.py restates
+    the contract; MLX itself is absent here: the bit layout is unpinned)."""
+    if bits not in (2, 4, 8):
+        raise CheckpointError(f"MLX quantisation with {bits} bits is not supported (2, 4, 8)")
+    per = 32 // bits
+    if wq.dtype not in (torch.uint32, torch.int32, torch.int64):
+        raise CheckpointError(f"quantised weight of dtype {wq.dtype}, expected uint32 packs")
+    out_f, packs = wq.shape
+    n_in = packs * per
+    if n_in % group_size != 0 or tuple(scales.shape) != (out_f, n_in // group_size) or tuple(biases.shape) != tuple(scales.shape):
+        raise CheckpointError(f"quantised weight {tuple(wq.shape)} does not match scales {tuple(scales.shape)} at group size {group_size}")
+    w64 = wq.to(torch.int64) & 0xFFFFFFFF
+    shifts = torch.arange(per, dtype=torch.int64) * bits
+    q = ((w64[:, :, None] >> shifts) & ((1 << bits) - 1)).reshape(out_f, n_in).to(torch.float32)
+    w = q.reshape(out_f, -1, group_size) * scales.float()[:, :, None] + biases.float()[:, :, None]
+    return w.reshape(out_f, n_in).to(torch.bfloat16)
+
+
+def mlx_quantized_checkpoint_to_reference(sd: StateDict, group_size: int = MLX_QUANT_GROUP, bits: int = MLX_QUANT_BITS) -> StateDict:
+    """The reference's ``...-4bit-quantized`` checkpoints hold MLX module-tree names already ("4-bit ckpt already adjusted",
+    mlx/model_io.py:772-775; SD3.5-large under the prefix ``model.diffusion_model.``, :728-734) with every ``nn.Linear`` stored as
+    ``weight`` (uint32 packs) / ``scales`` / ``biases`` (+ the Linear's own ``bias``).  The reference keeps them quantised and
+    multiplies through ``mx.quantized_matmul``; this engine dequantises once at load (bf16, or on to e4m3 when
+    ``MMDiTConfig.weight_dtype`` asks for the fp8 MFMA path): same values as ``mx.dequantize`` of the stored triplets."""
+    prefix = "model.diffusion_model."
+    if any(k.startswith(prefix) for k in sd):
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    out: StateDict = {}
+    for k, t in sd.items():
+        if k.endswith(".scales") or k.endswith(".biases"):
+            continue
+        stem = k[: -len(".weight")] if k.endswith(".weight") else None
+        if stem is not None and f"{stem}.scales" in sd:
+            if f"{stem}.biases" not in sd:
+                raise CheckpointError(f"{stem}: quantised weight without biases")
+            out[k] = dequantize_mlx(t, sd[f"{stem}.scales"], sd[f"{stem}.biases"], group_size, bits)
+        else:
+            out[k] = t
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # entry points used by the pipelines (local_ckpt={"mmdit": path_or_dict, "vae_decoder": path_or_dict})
 # ---------------------------------------------------------------------------------------------
 def load_mmdit_checkpoint(src, cfg: MMDiTConfig) -> StateDict:
     """``src``: a dict already in reference names, a raw checkpoint dict, or a .safetensors path."""
     sd = load_safetensors(src) if isinstance(src, str) else dict(src)
+    if any(k.endswith(".scales") for k in sd):  # an MLX nn.quantize checkpoint (the *-4bit-quantized model versions)
+        sd = mlx_quantized_checkpoint_to_reference(sd)
+        _check_mmdit_complete(sd, cfg)
+        return sd
     if any(k.startswith("multimodal_transformer_blocks.") for k in sd):
         return sd  # already remapped
     if any(k.startswith("double_blocks.") for k in sd):

@@ -23,6 +23,15 @@ Round 3 (VERDICT r2 "Next round" item 1: the configurations no parity test reach
                  block of the seeded 57-block weight set) on a seeded N(0, 1) joint stream of S = 4352 rows -> selected rows of
                  the block's output stream; a wrong fragment in one block cannot hide behind the conditioning of the stack
 
+Round 4 (VERDICT r3 "Next round" item 2: full depth beyond the schedule's first entries; gates that bite):
+  flux_dev_full  BASELINE configs[3] at FULL depth: 19 + 38 blocks at FLUX width, S_t = 512 (S = 4608), the 50-step schedule -- Euler steps
+                 1, 2, 49 and 50, each TEACHER-FORCED from a seeded latent x_i = sigma_i * noise + (1 - sigma_i) * x_clean (the
+                 reference's noise_scaling form, sampler.py:41-42), so that the oracle runs 4 forwards instead of 50 -> the Euler
+                 direction d_i = (x_i - denoised) / sigma_i of every step (what a step adds to the latent, not the latent it is added
+                 to); replayed with bf16 and with fp8 weights
+  sd3_full_late  BASELINE configs[2] at full depth (24 blocks, B = 2, CFG 5.0, 589 text tokens): steps 1, 25, 49 and 50 of the 50-step
+                 schedule the same way (late steps: small sigma, fp16-rounded timesteps 8.93 / 66.9)
+
 The fp32 oracle of the FLUX cases and of every round-3 case is the reference's function with fp32 ACTIVATIONS: its timestep
 embedding is still evaluated in config.dtype (mmdit.py:379-389, quirk Q2; bf16 for FLUX, fp16 for SD3) -- ``ref_model`` below.
 Round 2's FLUX fixtures used an oracle with an exact embedding and measured, at 27-32 dB, the distance between two different
@@ -92,6 +101,62 @@ FLUX_BLOCKS = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=256, ti
 # of the fp8 path (oracle/fp8.py); every 4th image token is kept
 FLUX_PAIR = dict(cfg=replace(FLUX_SCHNELL, depth_multimodal=1, depth_unified=1), seed_w=1234, B=1, latent=(128, 128), S_t=256,
                  timesteps=[1000.0, 752.0], step=1, row_stride=4)
+
+
+# ---- round 4 cases: teacher-forced Euler steps of the 50-step schedules at full depth -------------------------------------------
+FLUX_DEV_FULL = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=512, steps_of=50, shift=1.0, cfg_weight=0.0, flux=True,
+                     step_ids=(0, 1, 48, 49), noise_seed=0, clean_seed=91, text_seed=73, rows=1)
+SD3_FULL_LATE = dict(cfg=SD3_2b, seed_w=1234, latent=(128, 128), S_t=589, steps_of=50, shift=3.0, cfg_weight=5.0, flux=False,
+                     step_ids=(0, 24, 48, 49), noise_seed=0, clean_seed=92, text_seed=81, rows=2)
+
+
+def forced_inputs(c):
+    """conditioning rows and, per step id i, (x_i, sigma_i, sigma_{i+1}) of a teacher-forced step: x_i is what noise_scaling
+    (sampler.py:41-42) makes of a seeded clean latent at sigma_i"""
+    cfg = c["cfg"]
+    text = randn(c["rows"], c["S_t"], cfg.token_level_text_embed_dim, seed=c["text_seed"])
+    pooled = randn(c["rows"], cfg.pooled_text_embed_dim, seed=c["text_seed"] + 1)
+    sig = op.get_sigmas(c["shift"], c["flux"], c["steps_of"])
+    noise = op.get_noise(c["noise_seed"], *c["latent"])
+    clean = 0.8 * randn(1, c["latent"][0], c["latent"][1], 16, seed=c["clean_seed"])
+    steps = []
+    for i in c["step_ids"]:
+        s0 = sig[i]
+        steps.append((i, (s0 * noise + (1.0 - s0) * clean).to(torch.float32), sig[i: i + 2].clone()))
+    return text, pooled, steps
+
+
+def euler_direction(x_i, x_next, sig2):
+    """d_i = (x_i - denoised) / sigma_i, recovered from one Euler step x_next = x_i + d_i * (sigma_{i+1} - sigma_i)
+    (mlx/__init__.py:756,778-781)"""
+    return (x_next.double() - x_i.double()) / (float(sig2[1]) - float(sig2[0]))
+
+
+def make_forced(c, name, with_emu):
+    cfg = c["cfg"]
+    named = synth_mmdit_weights(cfg, seed=c["seed_w"])
+    w = LazyFloat(named) if cfg.is_flux else {k: v.float() for k, v in named.items()}
+    text, pooled, steps = forced_inputs(c)
+    t_act = None if c["flux"] else Prec(torch.float16)
+    out = {"step_ids": np.asarray(c["step_ids"])}
+    for pname, P in (("fp32", Prec()),) + ((("emu", Prec(BF)),) if with_emu else ()):
+        m = ref_model(cfg, w, P)
+        for i, x_i, sig2 in steps:
+            t0 = time.time()
+            x_next = op.sample_euler(m, x_i, sig2, text, pooled, c["cfg_weight"], Prec(BF), t_act=t_act)
+            d = euler_direction(x_i, x_next, sig2)
+            print(f"{name} {pname} step {i + 1}: {time.time() - t0:.0f} s, |d| rms {float(d.pow(2).mean().sqrt()):.3f}", flush=True)
+            if pname == "fp32":
+                out[f"d{i}_fp32_f16"] = d.numpy().astype(np.float16)
+                out[f"d{i}_rms"] = np.float64(d.pow(2).mean().sqrt())
+                keep = d
+                out.setdefault("_keep", {})[i] = keep
+            else:
+                ref = out["_keep"][i]
+                out[f"d{i}_emu_rel_l2"] = np.float64(rel_l2(ref, d))
+                out[f"d{i}_emu_psnr"] = np.float64(psnr(ref, d))
+    out.pop("_keep", None)
+    return out
 
 
 def ref_model(cfg, w, P):
@@ -322,7 +387,9 @@ CASES = {"flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_
          "flux_1024": lambda: make_forward(FLUX_1024, "flux_1024"), "flux_full": make_flux_full,
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,
-         "flux_blocks": make_flux_blocks}
+         "flux_blocks": make_flux_blocks,
+         "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", False),
+         "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True)}
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 8)

@@ -258,3 +258,69 @@ def test_reference_named_dict_passes_through():
     w = synth_mmdit_weights(cfg, seed=5)
     assert mio.load_mmdit_checkpoint(w, cfg) is not None
     same(mio.load_mmdit_checkpoint(w, cfg), w)
+
+
+# ---- MLX group-quantised checkpoints: the reference's *-4bit-quantized model versions (mlx/model_io.py:728-734,772-775) --------
+def to_mlx_quantized(w, prefix="", fast=True):
+    """reference-named weights -> an nn.quantize checkpoint: every Linear weight (2-D, input dimension a multiple of the group) becomes
+    weight (uint32 packs) / scales / biases, everything else (biases, norms, the patch conv, pos-emb) stays.  Returns the checkpoint
+    and, per quantised key, the fp32 matrix mx.dequantize gives back (oracle/mlxquant.py, element loops)."""
+    import numpy as np
+    from oracle import mlxquant as mq
+    ck, deq = {}, {}
+    for k, t in w.items():
+        if k.endswith(".weight") and t.dim() == 2 and t.shape[1] % 64 == 0 and "pos_embed" not in k and "norm" not in k:
+            wq, sc, bi = mq.quantize(t.float().numpy())
+            sc16, bi16 = torch.from_numpy(sc).to(torch.float16), torch.from_numpy(bi).to(torch.float16)  # the reference stores them in its 16-bit dtype
+            stem = k[: -len(".weight")]
+            ck[prefix + k] = torch.from_numpy(wq.astype(np.int64)).to(torch.uint32)
+            ck[prefix + stem + ".scales"], ck[prefix + stem + ".biases"] = sc16, bi16
+            deq[k] = torch.from_numpy(mq.dequantize(wq, sc16.float().numpy(), bi16.float().numpy()))
+        else:
+            ck[prefix + k] = t.contiguous()
+    return ck, deq
+
+
+@pytest.mark.parametrize("family", ["flux", "sd35"])
+def test_mlx_4bit_quantized_checkpoint_loads(tmp_path, family):
+    """a ...-4bit-quantized file (already in module-tree names; SD3.5 under model.diffusion_model.) comes back as bf16 weights equal
+    to mx.dequantize of its triplets, every other tensor bit for bit"""
+    from dataclasses import replace
+    from safetensors.torch import save_file
+    cfg = tiny_flux(depth_multimodal=1, depth_unified=1) if family == "flux" else replace(tiny_sd3(depth=1), use_qk_norm=True)
+    w = synth_mmdit_weights(cfg, seed=11)
+    ck, deq = to_mlx_quantized(w, "" if family == "flux" else "model.diffusion_model.")
+    assert len(deq) >= 10
+    path = os.path.join(tmp_path, f"{family}-4bit-quantized.safetensors")
+    save_file(ck, path)
+    got = mio.load_mmdit_checkpoint(path, cfg)
+    assert set(got) == set(w)
+    for k in w:
+        if k in deq:
+            assert got[k].dtype == torch.bfloat16
+            assert torch.equal(got[k], deq[k].to(torch.bfloat16)), k
+            # and the 4-bit grid is what it should be: within half a step of the original weight
+            assert (got[k].float() - w[k].float()).abs().max() <= 0.5 * (w[k].float().max() - w[k].float().min()) / 15 + 1e-2
+        else:
+            assert torch.equal(got[k], w[k]), k
+
+
+def test_mlx_dequantize_matches_oracle_loops_and_rejects_bad_shapes():
+    import numpy as np
+    from oracle import mlxquant as mq
+    g = torch.Generator().manual_seed(3)
+    for bits in (2, 4, 8):
+        w = torch.randn(5, 128, generator=g).numpy()
+        wq, sc, bi = mq.quantize(w, group_size=32, bits=bits)
+        ref = torch.from_numpy(mq.dequantize(wq, sc, bi, 32, bits))
+        got = mio.dequantize_mlx(torch.from_numpy(wq.astype(np.int64)).to(torch.uint32), torch.from_numpy(sc), torch.from_numpy(bi), 32, bits)
+        assert torch.equal(got, ref.to(torch.bfloat16))
+    # a pack whose top element has its high bit set (sign bit of the int32 view)
+    wq = np.array([[0xF0000001]], np.uint32)
+    ref = mq.dequantize(wq, np.ones((1, 1), np.float32), np.zeros((1, 1), np.float32), 8, 4)
+    got = mio.dequantize_mlx(torch.from_numpy(wq.astype(np.int64)).to(torch.uint32), torch.ones(1, 1), torch.zeros(1, 1), 8, 4)
+    assert got.float().tolist() == ref.tolist() == [[1.0, 0, 0, 0, 0, 0, 0, 15.0]]
+    with pytest.raises(mio.CheckpointError, match="scales"):
+        mio.dequantize_mlx(torch.zeros(4, 8, dtype=torch.uint32), torch.ones(4, 2), torch.zeros(4, 2))
+    with pytest.raises(mio.CheckpointError, match="biases"):
+        mio.mlx_quantized_checkpoint_to_reference({"a.weight": torch.zeros(4, 8, dtype=torch.uint32), "a.scales": torch.ones(4, 1)})
