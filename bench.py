@@ -151,7 +151,8 @@ def spawn_ranks(n):
 
 
 WORKLOAD_NAMES = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-dev-1024": "FLUX.1-dev 1024x1024 50-step",
-                  "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "tiny": "tiny"}
+                  "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "sd35-large-1024": "SD3.5-large 1024x1024 50-step CFG 5.0",
+                  "tiny": "tiny"}
 
 
 def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4):
@@ -165,7 +166,7 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
     import torch.distributed as dist
     from diffusionkit_amd import _lib
     from diffusionkit_amd import dist as dk
-    from diffusionkit_amd.config import FLUX_DEV, FLUX_SCHNELL, SD3_2b, VAEDecoderConfig, tiny_flux, tiny_vae
+    from diffusionkit_amd.config import FLUX_DEV, FLUX_SCHNELL, SD3_2b, SD3_8b, VAEDecoderConfig, tiny_flux, tiny_vae
     from diffusionkit_amd.pipeline import DiffusionPipeline, FluxPipeline
     from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
 
@@ -180,6 +181,11 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 0.0, 1.0, 512, 1
     elif workload == "sd3-medium-1024":
         cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 5.0, 3.0, 589, 2
+    elif workload == "sd35-large-1024":
+        # the reference's third model family (mlx/config.py:72-74, mlx/__init__.py:39): 38 blocks, 38 heads of 64 = h 2432 (9.5 column
+        # tiles of 256: the 256^2 GEMM's half-tile path), QK-norm; the CLI's SD3 settings (scripts/generate_images.py:15-40)
+        cfg, vcfg, cls, mv = SD3_8b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3.5-large"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 50, 5.0, 3.0, 589, 2
     else:
         cfg, vcfg, cls, mv = tiny_flux(), tiny_vae(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
@@ -348,7 +354,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "flux-dev-1024", "tiny"])
+    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "sd35-large-1024", "flux-dev-1024", "tiny"])
     ap.add_argument("--batch", default="1",
                     help="images per rank and step, denoised in one batched step loop (FLUX workloads).  Default 1 = BASELINE configs[1] "
                          "per GPU.  BASELINE configs[4] (FLUX.1-schnell, batch 64 sharded over 8 GPUs) is `--gpus 8 --batch 8`; "
@@ -397,7 +403,8 @@ def main():
     if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune:
         other = {}
         for key, (wl, fp8, n_img) in {"sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2),
-                                     "flux-dev-1024 fp8 (BASELINE configs[3])": ("flux-dev-1024", True, 2)}.items():
+                                     "flux-dev-1024 fp8 (BASELINE configs[3])": ("flux-dev-1024", True, 2),
+                                     "sd35-large-1024 (the reference's third model family, mlx/config.py:72-74)": ("sd35-large-1024", False, 1)}.items():
             r = run_workload(ctx, wl, fp8, 1, n_img, 1, want_roofline=not args.no_roofline, max_replay=1)
             rf = r["roofline"] or {}
             other[key] = {"metric": f"images/sec {WORKLOAD_NAMES[wl]}", "value": r["value"], "unit": "images/s", "steps": n_img, "warmup": 1,

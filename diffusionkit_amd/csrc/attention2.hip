@@ -299,11 +299,11 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn2_fwd_kernel(AttnParams p) 
 template <int D, int NW, bool HAS_BIAS = false, bool QFUSE = false>
 static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   using C = Attn2Cfg<D, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn2_fwd_kernel<D, NW, HAS_BIAS, QFUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      C::LDS_BYTES));
-    attr_set = true;
+    attr_once.mark();
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
   hipLaunchKernelGGL((dk_attn2_fwd_kernel<D, NW, HAS_BIAS, QFUSE>), dim3(nq * p.H * p.B), dim3(C::NT), C::LDS_BYTES, stream, p);

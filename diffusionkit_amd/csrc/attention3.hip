@@ -475,15 +475,15 @@ __global__ __launch_bounds__(NW * 64, 2) void dk_attn3_fwd_kernel(AttnParams p) 
 template <int D, int NW, bool QFUSE>
 static int launch_attn3(const AttnParams& p, hipStream_t stream) {
   using C = Attn3Cfg<D, NW>;
-  static bool attr_set = false;
+  static DkDeviceOnce attr_once;
   static int n_cu = 0;
-  if (!attr_set) {
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn3_fwd_kernel<D, NW, QFUSE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn3_fwd_kernel<D, NW, QFUSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     int dev = 0;
     DK_CHECK_HIP(hipGetDevice(&dev));
     DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+    attr_once.mark();
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
   const long tasks = (long)nq * p.H * p.B, nt = (p.S + 63) / 64;

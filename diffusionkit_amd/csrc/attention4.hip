@@ -440,10 +440,10 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 template <bool QFUSE>
 static int launch_attn4(const AttnParams& p, hipStream_t stream) {
   using C = Attn4Cfg;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn4_fwd_kernel<QFUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
+    attr_once.mark();
   }
   const int nq = (p.S + C::QB - 1) / C::QB;
   const long tasks = (long)nq * p.H * p.B;

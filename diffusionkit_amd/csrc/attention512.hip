@@ -256,10 +256,10 @@ int dk_launch_attention512(const Attn512Params& p, hipStream_t stream) {
   DK_REQUIRE(p.ld % 8 == 0 && p.ld >= A5_D && p.ldo % 4 == 0 && p.ldo >= A5_D, "attention512: row strides (16-byte aligned rows of >= 512 columns)");
   DK_REQUIRE(p.Tp % 8 == 0 && p.Tp >= (p.T + A5_KT - 1) / A5_KT * A5_KT, "attention512: V^T rows padded with zeros to a multiple of 32 keys");
   DK_REQUIRE((((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.Vt) & 15) == 0 && ((uintptr_t)p.O & 7) == 0, "attention512: alignment");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn512_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS_BYTES));
-    attr_set = true;
+    attr_once.mark();
   }
   dk_prof_begin(2, 4.0 * (double)p.B * (double)p.T * (double)p.T * A5_D, stream);
   hipLaunchKernelGGL(dk_attn512_fwd_kernel, dim3((unsigned)((p.T + A5_QB - 1) / A5_QB), (unsigned)p.B), dim3(512), A5_LDS_BYTES, stream, p);

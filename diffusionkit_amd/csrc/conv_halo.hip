@@ -515,12 +515,12 @@ bool dk_conv_halo_eligible(const ConvHaloParams& p, bool img) {
 int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream) {
   const bool img = p.img != nullptr || p.u8 != nullptr || p.raw != nullptr;
   DK_REQUIRE(dk_conv_halo_eligible(p, img), "conv_halo: shape / alignment not supported (H, W multiples of 16; C multiple of 64; O multiple of 128, or <= 4 for the image tail)");
-  static bool attr_set = false;
+  static DkDeviceOnce attr_once;
   constexpr int LDS128 = 2 * CH_A_SLOT + 3 * 128 * 128 + 8192, LDS16 = 2 * CH_A_SLOT + 3 * 16 * 128 + 8192;  // (+ the dummy store zone)
-  if (!attr_set) {
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_conv_halo_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_conv_halo_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS16));
-    attr_set = true;
+    attr_once.mark();
   }
   const long tiles = (long)p.B * (p.H >> 4) * (p.W >> 4);
   const double flops = 2.0 * p.B * p.H * p.W * (9.0 * p.C + (p.x2 ? p.C2 : 0)) * p.O;

@@ -139,3 +139,24 @@ __device__ __forceinline__ uint2 dk_mx8_quantize8(const float* v, unsigned& e8m0
   e8m0 = e;
   return make_uint2((unsigned)w0, (unsigned)w1);
 }
+
+// Launch-site setup that HIP keeps PER DEVICE (hipFuncSetAttribute of the dynamic-LDS limit): `static DkDeviceOnce once; if (once.first())
+// { ...; once.mark(); }` runs the block the first time each device of the process meets the call site (a plain static bool would set
+// the attribute on the first GPU only and launch with the 64 KiB default on the next).  Two threads racing through first() both
+// set the attribute: idempotent.
+#include <atomic>
+struct DkDeviceOnce {
+  std::atomic<unsigned long long> done{0ull};
+  static int device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : -1;
+  }
+  bool first() const {
+    const int dev = device();
+    return dev < 0 || (done.load(std::memory_order_acquire) & (1ull << dev)) == 0ull;
+  }
+  void mark() {
+    const int dev = device();
+    if (dev >= 0) done.fetch_or(1ull << dev, std::memory_order_release);
+  }
+};

@@ -58,7 +58,7 @@ extern int g_dk_v3_mf;     // gemm256v3.hip: wave-tile height in 16-row fragment
 // workspace of the remainder-wave K split (fp32 slabs + flags; its last 4 KiB -- the flag region -- must be zero before the first
 // launch; the kernels leave it zero)
 size_t dk_gemm_split_workspace_bytes();
-bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 256 == 0, K % 64 == 0, any M, any row-segment maps
+bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 128 == 0, K % 64 == 0, any M, any row-segment maps
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream);  // gemm256v3.hip (16x16x32 MFMA K loop)
 // two problems with the same N, K, epilogue in one launch (image + text stream of a double block); falls
@@ -244,6 +244,7 @@ int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream);
 // (gamma given) the per-channel table scale_shift [B][2][C]: scale = rstd * gamma, shift = beta - mean * scale
 int dk_launch_groupnorm_finalize(const float* partial, int nchunk, int B, int G, double count, float eps, float* mean_rstd,
                                  const bf16_t* gamma, const bf16_t* beta, int C, float* scale_shift, hipStream_t stream);
+int dk_launch_groupnorm_partials(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, hipStream_t stream);
 int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk,
                               float* mean_rstd, float eps, hipStream_t stream);
 int dk_launch_groupnorm_apply(const bf16_t* x, bf16_t* y, int B, long HW, int C, int G, const float* mean_rstd,

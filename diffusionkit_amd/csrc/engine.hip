@@ -284,9 +284,8 @@ extern "C" int dk_groupnorm_table_bf16(const void* x, int32_t B, int64_t HW, int
   DK_REQUIRE(x != nullptr || n_partial > 0, "either x or the number of partials a conv launch left in scratch");
   const int nchunk = x ? gn_nchunk((long)HW, C) : n_partial;
   float* mean_rstd = scratch + (size_t)B * (nchunk > 1024 ? nchunk : 1024) * 2 * G;
-  if (x) {
-    hipStream_t st = S_(stream);
-    const int rc = dk_launch_groupnorm_stats((const bf16_t*)x, B, (long)HW, C, G, scratch, nchunk, mean_rstd, eps, st);
+  if (x) {  // the partial sums only: the one finalisation below builds mean / rstd AND the table
+    const int rc = dk_launch_groupnorm_partials((const bf16_t*)x, B, (long)HW, C, G, scratch, nchunk, S_(stream));
     if (rc) return rc;
   }
   return dk_launch_groupnorm_finalize(scratch, nchunk, B, G, (double)HW * (double)(C / G), eps, mean_rstd, (const bf16_t*)gamma,
@@ -1212,6 +1211,10 @@ struct VaeRun {
   bool halo_stage(int H, int Wd, int Cin, int Cout) const {
     if (g_dk_conv_halo == 0 || H % 16 != 0 || Wd % 16 != 0 || Cin % 64 != 0 || Cout % 128 != 0) return false;
     if ((size_t)H * Wd * (Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return false;
+    // the fused stages always ask their conv for the output statistics of the next GroupNorm (dk_conv_halo_eligible: a channel
+    // group must divide the 128-channel workgroup tile and span at most 64 channels) -- other group plans take gn() + conv()
+    const int G = v->cfg.resnet_groups;
+    if (G <= 0 || Cout % G != 0 || 128 % (Cout / G) != 0 || Cout / G > 64) return false;
     return g_dk_conv_halo != 2 || Cout < 256;
   }
   // the (scale | shift) table of GroupNorm `name` over tensor x: from the partials the producing conv left, or a statistics pass
@@ -1333,7 +1336,7 @@ extern "C" int dk_vae_decode(dk_vae* v, const float* latent, int32_t batch, int3
   DK_TRY(R.conv(v->LAT, cur, H, W, 64, Cm, "conv_in", 0, nullptr, Cm));
   DK_TRY(R.resnet(cur, nxt, H, W, Cm, Cm, "mid_blocks.0")); std::swap(cur, nxt);
   DK_TRY(R.attention(cur, nxt, H, W, Cm, "mid_blocks.1")); std::swap(cur, nxt);
-  DK_TRY(R.resnet(cur, nxt, H, W, Cm, Cm, "mid_blocks.2")); std::swap(cur, nxt);
+  DK_TRY(R.resnet(cur, nxt, H, W, Cm, Cm, "mid_blocks.2", true)); std::swap(cur, nxt);  // (the first up-block's norm1 reads its partials)
   int C = Cm;
   // up_blocks list index n-1 runs first (vae.py:379,393); index 0 has no upsample conv
   for (int j = cf.n_blocks - 1; j >= 0; --j) {

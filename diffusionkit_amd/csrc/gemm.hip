@@ -268,7 +268,7 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   if (p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p)) {
     // implicit-GEMM convolutions with O % 256 == 0 ride the 256^2 kernel once their tiles fill most of the CUs (the VAE's 256^2-pixel
     // and larger stages); the 128^2-tile kernel below keeps the small stages and O = 128
-    const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     // (with the K-split workspace a stage of about half the CUs' worth of tiles goes there too: its tiles are cut in two along K)
     if (g_dk_gemm_mode == 9 || t256 >= 192 || (p.workspace != nullptr && t256 >= 96 && t256 <= 128)) return dk_launch_gemm256v3(p, nullptr, stream);
   }
@@ -283,11 +283,11 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   if (p.epi == DK_EPI_GATE_RES) DK_REQUIRE(p.gate && p.res, "gate/res missing");
   if (p.epi == DK_EPI_RES) DK_REQUIRE(p.res, "res missing");
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-    attr_set = true;
+    attr_once.mark();
   }
   dim3 grid(nbm * nbn), block(256);
   dk_prof_begin(p.conv ? 1 : 0, 2.0 * (double)p.M * (double)p.N * (double)p.K, stream);
@@ -308,7 +308,7 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
   if (g_dk_gemm_mode == -1 && same && (a.M >= 1024 || b.M >= 1024) && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
     // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial extra wave costs more
     // than the small separate launch) ...
-    const long ta = (long)((a.M + 255) / 256) * (a.N / 256), tb = (long)((b.M + 255) / 256) * (b.N / 256);
+    const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
     // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
     const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
     if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);

@@ -594,10 +594,10 @@ int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream
                    (p.n_split == 0 || (p2->epi2 == p.epi2 && p2->c2_mx8 == p.c2_mx8)),
                "grouped fp8 GEMM: N, K, epilogue must match");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256f8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    attr_once.mark();
   }
   const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
   const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;

@@ -3,7 +3,9 @@
 // column split; nn.Linear call sites python/src/diffusionkit/mlx/mmdit.py:821-832 and the fused linear1 / linear2
 // of the single-stream blocks (:693-751).
 //
-// Shapes: N % 256 == 0 and K % 64 == 0; M is free.  Rows go through the segment maps per lane on the load side
+// Shapes: N % 128 == 0 and K % 64 == 0; M is free.  (N % 256 == 128 -- SD3.5-large's h = 38 * 64 = 2432, config.py:72-74: the last
+// column tile is half a tile: its upper 128 weight rows are fetched as a second copy of the lower 128, so that every DMA piece stays
+// inside W, and the two waves columns that own them skip the tail.)  Rows go through the segment maps per lane on the load side
 // (clamped to the last row when M is ragged) and, in the tail, per tile when the tile lies inside one segment
 // (the common case) or per row when it straddles a segment boundary or the end of M -- the text stream of the
 // SD3 double blocks (B = 2 segments of 589 rows, mmdit.py:608-625) rides in the image stream's launch that way.
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   const bool second = tile >= tiles_a;
   const GemmParams& p = second ? pb : pa;
   const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
-  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / T256;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + T256 - 1) / T256;
 
   // ---- lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), chunk 4*kk + q ----
   unsigned offk[2];
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   }
   const char* gA = (const char*)p.A + (CONV ? (size_t)0 : (size_t)k0 * (BK * 2));
   const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw * 2 + (size_t)k0 * (BK * 2);
-  const size_t w128 = (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
+  // (half a column tile at the end of N: rows 128-255 of the weight slot are a second copy of rows 0-127)
+  const size_t w128 = n0 + T256 > p.N ? (size_t)0 : (size_t)128 * p.ldw * 2, w8 = (size_t)8 * p.ldw * 2;
+  const bool col_ok = n0 + wn * 64 < p.N;  // wave-uniform: this wave's 64 columns exist
 
   // LDS-DMA in the buffer form: SGPR resource (base, 4 GiB range) + 32-bit lane offset + scalar offset -- no 64-bit
   // per-lane address and no VALU per piece
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 
   // whole tiles: the bias of this lane's 16 columns (4 per 16-column fragment), all loads up front -- one latency, not one per pass
   u32x2 bias_q[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
-  if (piece < 0 && p.bias) {
+  if (piece < 0 && p.bias && col_ok) {
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) bias_q[nf] = *(const u32x2*)(p.bias + n0 + wn * 64 + nf * 16 + 4 * q);
   }
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         }
     }
     // (same wave writes and reads the image: program order + the compiler's lgkmcnt suffice)
-    if (!EMIT) return;
+    if (!EMIT || !col_ok) return;
     const int col = n0 + wn * 64 + ni * 32 + rc2 * 4;      // first of this lane's 8 columns of the GEMM (bias, gate, residual)
     const int ocol = ncol0 + wn * 64 + ni * 32 + rc2 * 4;  // the same inside the output it goes to
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gate8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -762,8 +766,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 }
 
 bool dk_gemm256v3_eligible(const GemmParams& p) {
-  if (p.M <= 0 || p.N % 256 != 0 || p.K % BK != 0 || (!p.conv && p.lda % 8 != 0) || p.ldw % 8 != 0 || p.ldc % 8 != 0) return false;
+  if (p.M <= 0 || p.N % 128 != 0 || p.K % BK != 0 || (!p.conv && p.lda % 8 != 0) || p.ldw % 8 != 0 || p.ldc % 8 != 0) return false;
   if (p.conv) {  // 3x3 / pad 1 / stride 1 (optionally over the nearest-x2 view); pixel packed as b:8 | y:12 | x:12, 31-bit byte offsets
+    if (p.N % 256 != 0) return false;  // (a half column tile would waste half the MFMAs of a 128-channel stage: the 128^2 kernel's)
     if (p.ups < 0 || p.ups > 1 || p.cC % BK != 0 || p.K != 9 * p.cC || p.M != p.cB * p.cH * p.cW || p.n_split != 0) return false;
     if (p.cB > 256 || p.cH > 4096 || p.cW > 4096 || (p.ups == 1 && (p.cH % 2 != 0 || p.cW % 2 != 0))) return false;
     if ((size_t)p.cB * (p.cH >> p.ups) * (p.cW >> p.ups) * p.cC * 2 >= (1ull << 31) || ((uintptr_t)p.A & 15) != 0) return false;
@@ -841,8 +846,8 @@ static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
   long cost[2];
   for (int mf = 7; mf <= 8; ++mf) {
     const int bm = 32 * mf;
-    long tiles = (long)((p.M + bm - 1) / bm) * (p.N / T256);
-    if (p2) tiles += (long)((p2->M + bm - 1) / bm) * (p2->N / T256);
+    long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
+    if (p2) tiles += (long)((p2->M + bm - 1) / bm) * ((p2->N + T256 - 1) / T256);
     cost[mf - 7] = ((tiles + n_cu - 1) / n_cu) * bm;
   }
   return cost[0] * 10 <= cost[1] * 9 ? 7 : 8;
@@ -850,9 +855,9 @@ static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
 
 // `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*tiles_a*/, int tiles_b_in, hipStream_t stream) {
-  static bool attr_set = false;
+  static DkDeviceOnce attr_once;
   static int n_cu = 0;
-  if (!attr_set) {
+  if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -860,13 +865,13 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
     int dev = 0;
     DK_CHECK_HIP(hipGetDevice(&dev));
     DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+    attr_once.mark();
   }
   const bool two = tiles_b_in > 0;
   const int mf = pick_mf(p, two ? &pb : nullptr, n_cu);
   const int bm = 32 * mf;
-  const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / T256);
-  const int tiles_b = two ? ((pb.M + bm - 1) / bm) * (pb.N / T256) : 0;
+  const int tiles_a = ((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
+  const int tiles_b = two ? ((pb.M + bm - 1) / bm) * ((pb.N + T256 - 1) / T256) : 0;
   // (a launch with the fused key QKNorm is never split: a split tile's finisher has no second pass over its row sums)
   const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0 &&
                        p.kn_w == nullptr && (!two || pb.kn_w == nullptr);

@@ -111,13 +111,19 @@ int dk_launch_groupnorm_finalize(const float* partial, int nchunk, int B, int G,
   DK_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, float* mean_rstd,
-                              float eps, hipStream_t stream) {
+// first pass alone: per (batch row, chunk, group) partial (sum, sum of squares)
+int dk_launch_groupnorm_partials(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, hipStream_t stream) {
   DK_REQUIRE(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "channels must be 8 * 2^k <= 2048");
   DK_REQUIRE(G <= 64 && C % G == 0, "groups");
   DK_REQUIRE(nchunk >= 1, "nchunk");
   hipLaunchKernelGGL(dk_gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, stream, x, HW, C, G, partial, nchunk);
   DK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int dk_launch_groupnorm_stats(const bf16_t* x, int B, long HW, int C, int G, float* partial, int nchunk, float* mean_rstd,
+                              float eps, hipStream_t stream) {
+  const int rc = dk_launch_groupnorm_partials(x, B, HW, C, G, partial, nchunk, stream);
+  if (rc) return rc;
   return dk_launch_groupnorm_finalize(partial, nchunk, B, G, (double)HW * (double)(C / G), eps, mean_rstd, nullptr, nullptr, C, nullptr, stream);
 }
 

@@ -114,6 +114,9 @@ def attention_d512(q: Tensor, k: Tensor, v: Tensor, scale: Optional[float] = Non
     for n, t in (("q", q), ("k", k), ("v", v)):
         _require_cuda(t, n, BF)
     B, T, Cc = q.shape
+    assert Cc == 512, f"attention_d512: head_dim {Cc}, the kernel is built for 512"
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        assert t.shape == q.shape and t.is_contiguous(), f"attention_d512: {n} must be a dense [B, T, 512] tensor (row pitch 512)"
     out = torch.empty_like(q)
     vt = torch.empty(B * 512 * lib.dk_attention_d512_tp(T), dtype=BF, device=q.device)
     scale = scale if scale is not None else 1.0 / math.sqrt(Cc)

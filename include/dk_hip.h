@@ -146,7 +146,8 @@ int dk_attention_set_workspace(void* workspace, size_t bytes);
 
 /* Single-head attention over head_dim 512: the VAE mid block's Attention (vae.py:28-57: softmax((q / sqrt 512) k^T) v over all
  * H * W tokens), flash-style -- the [T, T] score matrix of the reference (537 MB at T = 16384) is never written.  q / k / v / out:
- * bf16 [B, T, ld] (ld >= 512, multiple of 8); vt_scratch: B * 512 * dk_attention_d512_tp(T) bf16 (the kernel reads a transposed,
+ * bf16 [B, T, ld] with ld == 512 EXACTLY (dense rows: the transposed copy of v is taken from a dense [T, 512] matrix; any other row
+ * pitch is rejected) and ldo >= 512, a multiple of 8; vt_scratch: B * 512 * dk_attention_d512_tp(T) bf16 (the kernel reads a transposed,
  * zero-padded copy of v that this call writes there first). */
 int32_t dk_attention_d512_tp(int32_t T);
 int dk_attention_d512_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T, int32_t ld, int32_t ldo,

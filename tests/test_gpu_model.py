@@ -399,6 +399,19 @@ def test_sd3_width_cfg_batch(dev):
     psnr_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], "sd3 width")
 
 
+def test_sd35_large_width_cfg_batch(dev):
+    """SD3.5-large geometry at WIDTH (config.py:72-74: 38 heads of 64 = h 2432, QK-norm; N = 2432 / 7296 end in half a 256-column
+    tile on the 256^2 GEMM kernel, K = 2432 = 38 K-tiles), CFG batch 2, latent 64 x 64, S_t = 154, depth 2"""
+    from dataclasses import replace
+    from diffusionkit_amd.config import SD3_8b
+    cfg = replace(SD3_8b, depth_multimodal=2, hidden_size_override=38 * 64)
+    assert cfg.hidden_size == 2432 and cfg.head_dim == 64 and cfg.use_qk_norm
+    ts = [1000.0, 857.5]
+    eng, out, res = forward_case(cfg, dev, 2, 64, 64, 154, ts, 1)
+    yardstick_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], "sd3.5-large width")
+    psnr_ok(out.float(), res["emu"]["final"], res["fp32"]["final"], "sd3.5-large width")
+
+
 def test_vae_production_channels(dev):
     """Production VAE channel plan (128,256,512,512; 3 resnets/level) on a 16x16 latent -> 128x128."""
     from diffusionkit_amd.engine import VAEDecoderEngine
@@ -565,3 +578,9 @@ def test_decode_async_equals_inline_decode(dev):
         img, u8 = p.result()
         torch.cuda.synchronize()
         assert torch.equal(u8, w) and img.shape == (1, 64, 64, 3)
+    # the side stream's engine can be dropped and comes back on the next call
+    pipe.release_async_decoder()
+    assert not hasattr(pipe, "_async_decoder")
+    img, u8 = pipe.decode_async(lats[0]).result()
+    torch.cuda.synchronize()
+    assert torch.equal(u8, want[0])

@@ -126,6 +126,41 @@ def test_gemm_kernel_variants(dev, mode, epi):
     assert int(ws[-4096:].sum()) == 0
 
 
+@pytest.mark.parametrize("mf", [8, 7])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
+@pytest.mark.parametrize("M,N,K", [(1100, 384, 640), (2356, 2432, 2432)])
+def test_gemm_256_half_column_tile(dev, M, N, K, epi, mf):
+    """N % 256 == 128 on the 256^2 kernel (SD3.5-large's h = 38 * 64 = 2432, config.py:72-74: q / k / v, o_proj and fc2 end in half
+    a column tile): every output column against the oracle, and the bytes BEHIND the last column of each row untouched"""
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=21), randn(N, K, seed=22, scale=0.03), randn(N, seed=23, scale=0.1)
+    res, gate = randn(M, N, seed=24), randn(2, N, seed=25)
+    seg = (M + 1) // 2
+    acc = bf16r(x @ w.t() + b)
+    out = torch.full((M, N + 128), 7.0, dtype=BF, device=dev)  # row pitch N + 128: a store into the missing half tile would land here
+    ws = ops.gemm_workspace(dev)
+    try:
+        ops.tune("gemm", 9)
+        ops.tune("gemm_mf", mf)
+        if epi == "bias":
+            ops.linear(g(x, dev), g(w, dev), g(b, dev), out=out[:, :N], workspace=ws)
+            ref = acc
+        elif epi == "gelu":
+            ops.linear(g(x, dev), g(w, dev), g(b, dev), out=out[:, :N], epilogue=ops.DK_EPI_BIAS_GELU, workspace=ws)
+            ref = om.gelu_erf(acc, Prec())
+        else:
+            ops.linear(g(x, dev), g(w, dev), g(b, dev), out=out[:, :N], epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev),
+                       gate_seg_len=seg, workspace=ws)
+            ref = res + bf16r(gate.repeat_interleave(seg, 0)[:M] * acc)
+    finally:
+        ops.tune("gemm", -1)
+        ops.tune("gemm_mf", -1)
+    y = out[:, :N].float().cpu()
+    assert rel_l2(ref, y) < TOL_SINGLE_OP
+    assert max_abs(ref, y) < 0.02 * float(ref.abs().max()) + 1e-2
+    assert bool((out[:, N:] == 7.0).all())
+
+
 def test_gemm_256_joint_stream_in_place(dev):
     """The 256^2 kernel on the image rows of a joint [B, S, h] buffer (segment maps evaluated once per tile), C aliasing the
     residual as in post_sdpa."""
