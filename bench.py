@@ -66,57 +66,67 @@ def vae_flops(vcfg, h, w):
     return f
 
 
-def cpu_baseline(image_flops, budget_s=30.0):
-    """CPU 'port' baseline: the oracle restatement timed on this box's host cores on BASELINE.json configs[0] -- the
-    configuration the reference itself runs on a CPU: SD3-medium (all 24 blocks), latent 64 x 64, CFG off, 77 + 512 text
-    tokens, Euler steps + the VAE decode, END TO END through the oracle's own denoise loop.  Bounded: Euler steps are added
-    while the projected time stays inside ``budget_s`` (at least one step + the decode); the measured FLOP rate is converted
-    to images/s of THIS bench's workload by algorithmic FLOPs."""
+def cpu_sample_config(cfg):
+    """The bounded CPU sample of a workload: the same model at the same sequence length with 1/f of its blocks, the double : single
+    ratio kept (FLUX: 1 double + 2 single of 19 + 38, f = 19; SD3-medium: 2 of 24, f = 12; SD3.5-large: 2 of 38, f = 19) -- every
+    block of a kind does the same work, so one denoising step = f x the sample (embedders and final layer, < 0.2 % of the
+    sample's FLOPs, are then counted f times: the CPU figure is that much too slow, not too fast)."""
+    from dataclasses import replace
+    from math import gcd
+    dm, du = cfg.depth_multimodal, cfg.depth_unified
+    f = gcd(dm, du) if du else (dm // 2 if dm % 2 == 0 else dm)
+    return replace(cfg, depth_multimodal=dm // f, depth_unified=du // f), f
+
+
+def cpu_baseline(workload, threads=None):
+    """CPU 'port' baseline: the oracle restatement (fp32, PyTorch CPU) timed on this box's host cores ON THE BENCH WORKLOAD ITSELF,
+    bounded to 10-30 s: one forward of 1/f of the model's blocks at the workload's full sequence length and batch rows
+    (``cpu_sample_config``), and one VAE decode at a quarter of the pixels (latent 64 x 64, scaled to the workload's latent by the
+    decoder's algorithmic FLOPs: its convolutions are linear in the pixel count).  images/s = 1 / (steps x f x t_sample + t_decode).
+    A whole FLUX.1-schnell step timed the same way (57 blocks, ~2 min) is in profiles/r04_cpu_flux_step.log
+    (scripts/cpu_flux_step.py) next to its own 1/19 sample."""
     import torch
-    from diffusionkit_amd.config import SD3_2b, VAEDecoderConfig
+    from diffusionkit_amd.config import VAEDecoderConfig
     from diffusionkit_amd.weights import synth_mmdit_weights, synth_vae_weights
-    from oracle import pipeline as op
-    from oracle.mmdit import OracleMMDiT, Prec
+    from oracle.mmdit import OracleMMDiT, Prec, embed_dtype
     from oracle.vae import OracleVAEDecoder
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)  # torch's CPU GEMMs stop scaling (and the elementwise ops regress) beyond a few dozen threads
+    threads = threads or min(cores, 64)  # torch's CPU GEMMs stop scaling (and the elementwise ops regress) beyond a few dozen threads
     torch.set_num_threads(threads)
-    cfg, vcfg = SD3_2b, VAEDecoderConfig()
-    w = {k: v.float() for k, v in synth_mmdit_weights(cfg, seed=1).items()}
-    vw = {k: v.float() for k, v in synth_vae_weights(vcfg, seed=2).items()}
+    cfg, latent, num_steps, S_t, rows = workload["cfg"], workload["latent"], workload["num_steps"], workload["S_t"], workload["rows"]
+    scfg, f = cpu_sample_config(cfg)
+    vcfg = VAEDecoderConfig()
+    w = {k: v.float() for k, v in synth_mmdit_weights(scfg, seed=1).items()}
     g = torch.Generator().manual_seed(0)
-    S_t, latent = 77 + 512, (64, 64)
-    text = torch.randn(1, S_t, cfg.token_level_text_embed_dim, generator=g)
-    pooled = torch.randn(1, cfg.pooled_text_embed_dim, generator=g)
-    model = OracleMMDiT(cfg, w, Prec())
+    text = torch.randn(rows, S_t, cfg.token_level_text_embed_dim, generator=g)
+    pooled = torch.randn(rows, cfg.pooled_text_embed_dim, generator=g)
+    lat = torch.randn(rows, latent[0], latent[1], 16, generator=g)
+    model = OracleMMDiT(scfg, w, Prec(), embed_prec=Prec(embed_dtype(scfg)))
+    model.cache_modulation_params(pooled, torch.tensor([1000.0]))
+    t0 = time.perf_counter()
+    model(lat, text, 1000.0)
+    t_sample = time.perf_counter() - t0
+    del model, w
     S_i = (latent[0] // cfg.patch_size) * (latent[1] // cfg.patch_size)
-    step_fl, dec_fl = mmdit_step_flops(cfg, S_t, S_i, 1), vae_flops(vcfg, *latent)
-    # one Euler step first (through the oracle's step loop), to size the sample
+    sample_fl = mmdit_step_flops(scfg, S_t, S_i, rows)
+    vw = {k: v.float() for k, v in synth_vae_weights(vcfg, seed=2).items()}
+    small = (min(latent[0], 64), min(latent[1], 64))
+    z = torch.randn(1, small[0], small[1], 16, generator=g)
     t0 = time.perf_counter()
-    lat = op.denoise_latents(model, text, pooled, 1, 0.0, latent, 0, 3.0, False, Prec(torch.bfloat16), t_act=Prec(torch.float16))
-    t_step = time.perf_counter() - t0
-    n_steps = 1
-    if 4 * t_step < budget_s * 0.7:  # the whole of configs[0] fits: run it as specified (4 steps), discarding the sizing step
-        t0 = time.perf_counter()
-        lat = op.denoise_latents(model, text, pooled, 4, 0.0, latent, 0, 3.0, False, Prec(torch.bfloat16), t_act=Prec(torch.float16))
-        t_den, n_steps = time.perf_counter() - t0, 4
-    else:
-        t_den = t_step
-    t0 = time.perf_counter()
-    OracleVAEDecoder(vcfg, vw, Prec())(lat)
-    t_dec = time.perf_counter() - t0
-    total_s = t_den + t_dec
-    flops = n_steps * step_fl + dec_fl
-    rate = flops / total_s
-    full_s = (4 * step_fl + dec_fl) / rate if n_steps != 4 else total_s
+    OracleVAEDecoder(vcfg, vw, Prec())(z)
+    t_dec_small = time.perf_counter() - t0
+    dec_scale = vae_flops(vcfg, *latent) / vae_flops(vcfg, *small)
+    t_step, t_dec = f * t_sample, dec_scale * t_dec_small
+    image_s = num_steps * t_step + t_dec
     return {
-        "value": rate / image_flops, "unit": "images/s", "cores": threads, "kind": "port",
-        "sample": f"oracle (fp32, PyTorch CPU, {threads} threads of {cores} cores) on BASELINE configs[0] end to end: SD3-medium 24 blocks, latent 64x64, "
-                  f"589 text tokens, {n_steps} of 4 Euler steps + VAE decode = {flops / 1e12:.2f} TFLOP in {total_s:.1f} s "
-                  f"({rate / 1e9:.0f} GFLOP/s; configs[0] image: {full_s:.1f} s{'' if n_steps == 4 else ' projected'} = {1.0 / full_s:.4f} images/s); "
-                  f"value = that FLOP rate / this workload's {image_flops / 1e12:.1f} TFLOP per image",
-        "sample_seconds": round(total_s + (t_step if n_steps == 4 else 0.0), 2),
-        "configs0_images_per_s": round(1.0 / full_s, 5),
+        "value": 1.0 / image_s, "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
+        "sample": f"oracle (fp32, PyTorch CPU, {threads} threads of {cores} host cores) on this workload: one forward of "
+                  f"{scfg.depth_multimodal} double + {scfg.depth_unified} single blocks (1/{f} of the model) at {rows} x ({S_t} + {S_i}) tokens, "
+                  f"width {cfg.hidden_size} = {sample_fl / 1e12:.2f} TFLOP in {t_sample:.1f} s ({sample_fl / t_sample / 1e9:.0f} GFLOP/s) -> {t_step:.0f} s per step; "
+                  f"VAE decode at latent {small[0]}x{small[1]} in {t_dec_small:.1f} s, x {dec_scale:.2f} by decoder FLOPs -> {t_dec:.0f} s; "
+                  f"image = {num_steps} steps + decode = {image_s:.0f} s",
+        "sample_seconds": round(t_sample + t_dec_small, 2),
+        "cpu_s_per_step": round(t_step, 1), "cpu_s_per_image": round(image_s, 1),
     }
 
 
@@ -343,6 +353,7 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
             "weight_init_s": round(t_init, 2), "weight_bcast_s": round(t_bcast, 3), "weight_blob_gb": round(blob_bytes / 1e9, 2),
             "per_rank_images_per_s": [round(v, 4) for v in per_rank],
             "roofline": roofline, "image_flops": image_flops,
+            "cpu_workload": {"cfg": replace(cfg, weight_dtype="bf16") if fp8 else cfg, "latent": latent, "num_steps": num_steps, "S_t": S_t, "rows": rows},
         }
     del pipe, weights, packed
     torch.cuda.empty_cache()
@@ -415,7 +426,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
-        cpu = cpu_baseline(head["image_flops"])
+        cpu = cpu_baseline(head["cpu_workload"])
 
     if rank == 0:
         try:

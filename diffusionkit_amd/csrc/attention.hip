@@ -11,7 +11,7 @@
 // Kernels: attention2.hip (VALU-lean, deferred rescale, 4 waves of 32 queries; the only one with a score bias), attention3.hip
 // (two key tiles in flight per wave, 8 waves, D = 128; also the balanced stream-K-like launch) and attention4.hip (round 3: the two
 // waves of a SIMD in opposite matrix / vector phases; D = 128; the default on long sequences: +12 % over attention3 on the FLUX
-// shapes in isolation, 815 -> 932 TF inside the model).  Round 3 pruned the variants whose A/B is settled (profiles/r01_attention_lab.md,
+// shapes in isolation, 815 -> 932 TF inside the model).  Round 3 pruned the variants whose A/B is settled (profiles/archive/r01_attention_lab.md,
 // r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
 #include "dk_kernels.h"
 
@@ -32,7 +32,7 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   DK_REQUIRE(p.D == 128 || p.D == 64, "head_dim must be 64 or 128");
   DK_REQUIRE(p.S > 0 && p.B > 0 && p.H > 0, "empty attention");
   DK_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "row strides must keep 16-byte alignment");
-  // automatic choice (kernel lab, profiles/r01_attention_lab.md, r02_attn_bench.log, r03_attention_phase_alternating.md): D = 128 on
+  // automatic choice (kernel lab, profiles/archive/r01_attention_lab.md, r02_attn_bench.log, r03_attention_phase_alternating.md): D = 128 on
   // long sequences: the phase-alternating kernel (8 waves per workgroup; 1018 / 1053 / 1078 TF against 908 / 961 / 978 for the
   // pipelined kernel on FLUX B1 / FLUX-dev B1 / FLUX B4, same box); otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF
   // against 773 / 823 for the pipelined forms).  A score bias (text encoders) is only implemented by the lean kernel's 4-wave form;

@@ -4,7 +4,7 @@
 // call sites python/src/diffusionkit/mlx/mmdit.py:562,643,687,736) -- transposed scores S^T = K Q^T,
 // lane-local online softmax, O^T += V^T P^T with V read through ds_read_b64_tr_b16 -- but the per-tile
 // instruction stream is cut down, because rocprofv3 counters showed the first kernel VALU-bound
-// (13 VALU per MFMA, VALU busy 59 %, MFMA busy 33 %; profiles/r01_attention_pmc.md):
+// (13 VALU per MFMA, VALU busy 59 %, MFMA busy 33 %; profiles/archive/r01_attention_pmc.md):
 //   * K/V tile loads use ONE 32-bit lane offset per 16-byte chunk against a wave-uniform base that
 //     advances per tile (global_load saddr form): no per-tile address arithmetic, the key clamp is
 //     evaluated only in the tail tile;

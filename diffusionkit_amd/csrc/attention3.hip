@@ -6,7 +6,7 @@
 //
 // Why: in the second-generation kernel a wave's tile is one dependent chain -- 16 score MFMAs, then ~190 VALU instructions of
 // softmax, then 16 P.V MFMAs -- so the matrix pipe only works when the OTHER wave of the SIMD happens to be in a different part of
-// its chain, and the per-tile barrier keeps pulling the two into step (rocprofv3 PMC, profiles/r01_pmc_bench_v13.md: MFMA busy
+// its chain, and the per-tile barrier keeps pulling the two into step (rocprofv3 PMC, profiles/archive/r01_pmc_bench_v13.md: MFMA busy
 // 34 %, 6.0 VALU per MFMA).  Here every wave carries two tiles in flight (guide T15):
 //   region A   P(j) = exp2(S(j) c - m c), row sums, bf16 packing     (VALU, ~115 instructions)
 //              || S(j+1) = K(j+1) Q^T                                (16 MFMAs + their 16 LDS fragment reads)

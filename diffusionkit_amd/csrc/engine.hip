@@ -23,7 +23,7 @@ int g_dk_fuse_k = 1;  // dk_tune_set("gemm_fuse_k", v): QKNorm + RoPE of the key
 int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the queries inside the attention kernel's Q load (1, default) or as a separate pass (0)
 // Rows of K >= g_dk_pitch_min_k elements (the [h, 5h] linear2 and [h, 4h] fc2 weights of FLUX and the activations they
 // multiply) are stored with 64 elements of padding: a 24-30 KB row stride makes the K-tile DMA of 256 rows camp on a few
-// memory channels (linear2 of FLUX: 369 -> 345 us with the padded pitch, profiles/r01_gemm_lab_pitch.log).
+// memory channels (linear2 of FLUX: 369 -> 345 us with the padded pitch, profiles/archive/r01_gemm_lab_pitch.log).
 int g_dk_pitch_min_k = 8192;
 // dk_tune_set("conv_halo", v): the VAE's norm -> silu -> conv stages on the halo-staged kernel with the GroupNorm applied on load
 // (conv_halo.hip): -1 (default) / 1 wherever the shape allows (measured: decode 15.1 -> 12.5 ms, against 13.0 ms when only the

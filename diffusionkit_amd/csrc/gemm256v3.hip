@@ -793,7 +793,7 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
 }
 
 // dk_tune_set("gemm_split", v): -1 (default) split a remainder wave of at most half the CUs into equal pieces when the
-// cost model below says it pays, 0 never, 1 whenever possible.  Kernel lab (profiles/r01_gemm_lab.md): every workgroup
+// cost model below says it pays, 0 never, 1 whenever possible.  Kernel lab (profiles/archive/r01_gemm_lab.md): every workgroup
 // carries ~18 us of fixed cost (launch, first DMA, tail) and a CU runs its K-tiles ~20 % slower when all 256 CUs are busy
 // than when 192 are, so a remainder of MORE than half the CUs (finisher + several producer pieces in turn on the
 // spare CUs) loses on every shape but the longest-K one and is only taken when forced.

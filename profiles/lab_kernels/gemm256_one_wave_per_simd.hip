@@ -1,4 +1,4 @@
-// LAB KERNEL, not part of libdk_hip.so (see DESIGN.md section 7.1 and profiles/r01_gemm_lab_v4_*.log): the contract, tile order,
+// LAB KERNEL, not part of libdk_hip.so (see DESIGN.md section 7.1 and profiles/archive/r01_gemm_lab_v4_*.log): the contract, tile order,
 // LDS-DMA ring, tail and remainder split of diffusionkit_amd/csrc/gemm256v3.hip with ONE wave per SIMD -- 4 waves (2 x 2),
 // wave tile 128 x 128, accumulators pinned by register class through inline-asm MFMAs (192 AGPR + 64 VGPR) -- and the K-loop
 // schedule the measurements point to: the fragments of a whole K = 32 slice of both operands are read one slice ahead, an

@@ -25,21 +25,24 @@ from tests._util import BF, psnr, rel_l2  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 # ---- stated tolerances ------------------------------------------------------------------------------
+# Round 4: every gate sits at the value measured on MI355X (profiles/r03_fullsize_parity.log) minus 2 dB of
+# PSNR / times 1.5 in relative L2 -- a regression of one bf16 rounding point per stored tensor fails.  The fp8 rows are gated at
+# the same distance from THEIR measurement (the un-quantised oracle is 33-37 dB away by construction, section 4).
 TOL = {
     # case: (min PSNR dB, max rel-L2) of the HIP result against the fp32 oracle
-    "sd3_512_latent": (45.0, 2.5e-2),   # BASELINE configs[0]: 24 blocks x 4 steps, final latent
-    "sd3_512_image": (35.0, None),      # ... decoded 512 x 512 image in [0, 1] (the reference's torch<->CoreML bar)
-    "vae_1024_image": (40.0, None),     # full-size decode, image in [0, 1]
-    "vae_1024_raw": (None, 4.0e-2),     # ... decoder output before the clip
-    "sd3_1024_final": (45.0, 2.5e-2),   # SD3 bench shape, depth 2, model output
-    "flux_1024_final": (45.0, 2.5e-2),  # FLUX depth 4 + 8 at S = 4352 (round 3: oracle with the reference's bf16 timestep embedding; emu 50.4 dB / 1.15e-2)
-    "flux_1024_fp8_final": (30.0, 8.0e-2),  # ... with e4m3 weights / MX-fp8 activations against the fp32 oracle with the ORIGINAL weights
+    "sd3_512_latent": (49.8, 1.65e-2),   # BASELINE configs[0]: 24 blocks x 4 steps, final latent
+    "sd3_512_image": (47.5, None),      # ... decoded 512 x 512 image in [0, 1] (the reference's torch<->CoreML bar)
+    "vae_1024_image": (47.6, None),     # full-size decode, image in [0, 1]
+    "vae_1024_raw": (None, 2.6e-2),     # ... decoder output before the clip
+    "sd3_1024_final": (50.5, 1.75e-2),   # SD3 bench shape, depth 2, model output
+    "flux_1024_final": (48.3, 1.7e-2),  # FLUX depth 4 + 8 at S = 4352 (round 3: oracle with the reference's bf16 timestep embedding; emu 50.4 dB / 1.15e-2)
+    "flux_1024_fp8_final": (31.6, 1.0e-1),  # ... with e4m3 weights / MX-fp8 activations against the fp32 oracle with the ORIGINAL weights
     # ---- round 3 ----
-    "flux_dev_512_final": (45.0, 2.5e-2),      # configs[3]'s shape (S_t 512, S 4608), 1 + 1 blocks, bf16 weights (emu 54.3 dB / 8.7e-3)
-    "flux_dev_512_fp8_final": (32.0, 8.0e-2),  # ... e4m3 weights / MX-fp8 activations against the fp32 oracle with the original weights
-    "sd3_full_1024_x3": (60.0, 5.0e-3),         # configs[2] at full depth: 24 blocks, B 2, CFG 5, first 3 of 50 Euler steps
-    "flux_full_latent": (45.0, 2.5e-2),      # BASELINE configs[1] end to end (57 blocks x 4 steps), round-3 fixture (the reference's bf16 timestep embedding in the oracle)
-    "flux_full_fp8_latent": (32.0, 1.0e-1),  # the same image with e4m3 weights / MX-fp8 activations on every block Linear
+    "flux_dev_512_final": (52.3, 1.28e-2),      # configs[3]'s shape (S_t 512, S 4608), 1 + 1 blocks, bf16 weights (emu 54.3 dB / 8.7e-3)
+    "flux_dev_512_fp8_final": (34.9, 9.0e-2),  # ... e4m3 weights / MX-fp8 activations against the fp32 oracle with the original weights
+    "sd3_full_1024_x3": (71.2, 1.6e-3),         # configs[2] at full depth: 24 blocks, B 2, CFG 5, first 3 of 50 Euler steps
+    "flux_full_latent": (52.4, 1.28e-2),      # BASELINE configs[1] end to end (57 blocks x 4 steps), round-3 fixture (the reference's bf16 timestep embedding in the oracle)
+    "flux_full_fp8_latent": (35.3, 9.0e-2),  # the same image with e4m3 weights / MX-fp8 activations on every block Linear
 }
 
 
@@ -95,7 +98,7 @@ def start_synth_prefetch():
     if _SYNTH_THREAD:
         return
     small = []
-    for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 1)):
+    for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 2)):
         small.append((_synth_key(c["cfg"], c["seed_w"]), c["cfg"], c["seed_w"], uses))
     big = [(_synth_key(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"]), fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], 1)]
     _SYNTH_PLAN.extend(big + small)
@@ -129,6 +132,38 @@ def flux_full_synth():
     if "w" not in _FLUX_SYNTH:
         _FLUX_SYNTH["w"] = synth_cached(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], keep=True)
     return _FLUX_SYNTH["w"]
+
+
+_FLUX_PIPES = {}
+
+
+def flux_full_pipe(dev, fp8=False):
+    """the full-depth FLUX.1-schnell pipeline on the seeded weight set, packed once per session and weight dtype (24 GB bf16 /
+    12 GB e4m3): shared by the end-to-end cases, the teacher-forced blocks and the teacher-forced Euler steps"""
+    if fp8 not in _FLUX_PIPES:
+        from dataclasses import replace
+        from diffusionkit_amd.pipeline import FluxPipeline
+        c = fx.FLUX_FULL
+        cfg = replace(c["cfg"], weight_dtype="fp8_e4m3") if fp8 else c["cfg"]
+        packed = {"mmdit": pack_mmdit(cfg, flux_full_synth(), dev)}
+        _FLUX_PIPES[fp8] = FluxPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed, mmdit_config=cfg)
+    return _FLUX_PIPES[fp8]
+
+
+def forced_steps(pipe, c, dev):
+    """Euler directions d_i of the teacher-forced steps of ``c`` (tests/golden/make_fullsize_fixtures.py: forced_inputs) through the
+    pipeline's own sample_euler / CFGDenoiser, one two-entry schedule per step"""
+    from diffusionkit_amd.pipeline import CFGDenoiser, sample_euler
+    text, pooled, steps = fx.forced_inputs(c)
+    extra = {"conditioning": text.to(dev, BF), "cfg_weight": c["cfg_weight"], "pooled_conditioning": pooled.to(dev, BF)}
+    sig_pipe = np.asarray(pipe.get_sigmas(pipe.sampler, c["steps_of"]), dtype=np.float64)
+    out = {}
+    for i, x_i, sig2 in steps:
+        assert np.allclose(sig_pipe[i: i + 2], sig2.numpy().astype(np.float64), rtol=0, atol=1e-7)  # the pipeline's own schedule entries
+        x_next, it = sample_euler(CFGDenoiser(pipe), x_i.to(dev), sig2.numpy(), extra_args=dict(extra))
+        assert len(it) == 1
+        out[i] = fx.euler_direction(x_i, x_next.float().cpu(), sig2)
+    return out
 
 
 def test_sd3_medium_512_full_depth_pipeline(dev):
@@ -201,11 +236,9 @@ def test_flux_1024_depth_4_8_fp8_weights_vs_oracle(dev):
 
 def test_flux_schnell_1024_full_depth_pipeline(dev):
     """BASELINE configs[1] end to end: FLUX.1-schnell, 19 + 38 blocks, latent 128 x 128, 4 Euler steps, vs the fp32 oracle's latent"""
-    from diffusionkit_amd.pipeline import FluxPipeline
     f = load("flux_full")
     c = fx.FLUX_FULL
-    packed = {"mmdit": pack_mmdit(c["cfg"], flux_full_synth(), dev)}
-    pipe = FluxPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
+    pipe = flux_full_pipe(dev)
     text, pooled = fx.flux_full_inputs()
     lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
                                   seed=c["noise_seed"])
@@ -215,13 +248,9 @@ def test_flux_schnell_1024_full_depth_pipeline(dev):
 def test_flux_schnell_1024_full_depth_pipeline_fp8_weights(dev):
     """BASELINE configs[1]'s image with configs[3]'s arithmetic: FLUX.1-schnell, 19 + 38 blocks, 4 Euler steps, e4m3 weights and
     MX-fp8 activations on every block Linear, against the fp32 oracle's latent (original weights)"""
-    from dataclasses import replace
-    from diffusionkit_amd.pipeline import FluxPipeline
     f = load("flux_full")
     c = fx.FLUX_FULL
-    cfg = replace(c["cfg"], weight_dtype="fp8_e4m3")
-    packed = {"mmdit": pack_mmdit(cfg, flux_full_synth(), dev)}
-    pipe = FluxPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed, mmdit_config=cfg)
+    pipe = flux_full_pipe(dev, fp8=True)
     text, pooled = fx.flux_full_inputs()
     lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
                                   seed=c["noise_seed"])
@@ -273,12 +302,6 @@ def test_sd3_medium_1024_full_depth_cfg_first_steps(dev):
     check("sd3_full_1024_x3", torch.from_numpy(f["x_step3_fp32"]), x3.float().cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
 
 
-def _flux_full_engine(dev, weights, cfg=None):
-    from diffusionkit_amd.engine import MMDiTEngine
-    cfg = cfg or fx.FLUX_FULL["cfg"]
-    return MMDiTEngine(cfg, pack_mmdit(cfg, weights, dev))
-
-
 def test_flux_full_size_blocks_teacher_forced(dev):
     """The FLUX gate that bites: single blocks of the full-size 57-block model (first double, last double, one
     single block; their own weights and modulation rows) teacher-forced through dk_mmdit_run_blocks on a seeded N(0, 1) joint
@@ -287,7 +310,7 @@ def test_flux_full_size_blocks_teacher_forced(dev):
     the same block, and against an absolute ceiling."""
     f = load("flux_blocks")
     c = fx.FLUX_BLOCKS
-    eng = _flux_full_engine(dev, flux_full_synth())
+    eng = flux_full_pipe(dev).mmdit
     x, pooled = fx.flux_blocks_inputs()
     eng.prepare(1, c["latent"], c["S_t"], len(c["timesteps"]))
     eng.cache_modulation_params(pooled.to(dev), c["timesteps"])
@@ -301,12 +324,59 @@ def test_flux_full_size_blocks_teacher_forced(dev):
         emu, emu_delta = float(f[f"block{g}_emu_rel_l2"]), float(f[f"block{g}_emu_rel_l2_delta"])
         print(f"[fullsize] flux block {g}: rel-L2 of the output stream {e:.3e} (bf16-emulating oracle {emu:.3e}), of the block's "
               f"contribution {e_delta:.3e} (emu {emu_delta:.3e}; contribution / output = {float(f[f'block{g}_delta_over_out']):.3f})")
-        assert e <= 5e-3, f"block {g}: rel-L2 {e:.3e} > 5e-3"
+        assert e <= 4.5e-3, f"block {g}: rel-L2 {e:.3e} > 4.5e-3"  # measured 2.8e-3 ... 3.2e-3
         assert e_delta <= 1.5 * emu_delta + 2e-3, f"block {g}: contribution error {e_delta:.3e} vs emulation {emu_delta:.3e}"
     # two consecutive blocks through the range entry = the two single calls chained (the range loop itself)
     y01 = eng.run_blocks(xd, c["step"], 18, 2)
     y0 = eng.run_blocks(xd, c["step"], 18, 1)
     assert torch.equal(eng.run_blocks(y0, c["step"], 19, 1), y01)
+
+
+# ---- round 4: full depth beyond the schedule's first entries (VERDICT r3 "Next round" item 2) ------------------------------------
+FORCED_TOL = {
+    # case: (min PSNR dB, max rel-L2) of every step's Euler direction d_i against the fp32 oracle's
+    "flux_dev_full": (48.0, 1.6e-2),
+    "flux_dev_full_fp8": (30.0, 1.3e-1),
+    "sd3_full_late": (40.0, 2.0e-2),
+}
+
+
+def check_forced(name, f, got, tol_key):
+    worst_p, worst_e = 1e9, 0.0
+    for i in sorted(got):
+        ref = torch.from_numpy(f[f"d{i}_fp32_f16"].astype(np.float32))
+        p, e = psnr(ref, got[i].float()), rel_l2(ref, got[i].float())
+        emu = f", bf16-emulating oracle {float(f[f'd{i}_emu_psnr']):.2f} dB / {float(f[f'd{i}_emu_rel_l2']):.3e}" if f"d{i}_emu_psnr" in f.files else ""
+        print(f"[fullsize] {name} step {i + 1} of 50: Euler direction PSNR {p:.2f} dB, rel-L2 {e:.4e} (|d| rms {float(f[f'd{i}_rms']):.3f}{emu})")
+        worst_p, worst_e = min(worst_p, p), max(worst_e, e)
+    min_p, max_e = FORCED_TOL[tol_key]
+    assert worst_p >= min_p, f"{name}: PSNR {worst_p:.2f} dB < {min_p}"
+    assert worst_e <= max_e, f"{name}: rel-L2 {worst_e:.3e} > {max_e}"
+
+
+def test_flux_dev_full_depth_st512_forced_steps(dev):
+    """BASELINE configs[3] at FULL depth (19 + 38 blocks, S_t = 512, S = 4608): Euler steps 1, 2, 49 and 50 of the 50-step schedule,
+    each teacher-forced from a seeded latent at its sigma, bf16 weights -- the Euler direction of every step against the fp32 oracle"""
+    f = load("flux_dev_full")
+    check_forced("flux_dev_full", f, forced_steps(flux_full_pipe(dev), fx.FLUX_DEV_FULL, dev), "flux_dev_full")
+
+
+def test_flux_dev_full_depth_st512_forced_steps_fp8_weights(dev):
+    """... with configs[3]'s arithmetic (e4m3 weights, MX-fp8 activations on every block Linear) against the same fp32 oracle
+    (original weights): the distance is the format's quantisation noise over 57 blocks, reported and gated at its measured level"""
+    f = load("flux_dev_full")
+    check_forced("flux_dev_full fp8", f, forced_steps(flux_full_pipe(dev, fp8=True), fx.FLUX_DEV_FULL, dev), "flux_dev_full_fp8")
+
+
+def test_sd3_medium_1024_full_depth_cfg_late_steps(dev):
+    """BASELINE configs[2] at full depth (24 blocks, B = 2, CFG 5.0, 589 text tokens): steps 1, 25, 49 and 50 of the 50-step
+    schedule, teacher-forced -- the late steps run the fp16-rounded small timesteps (66.9, 8.93) no other full-depth case reaches"""
+    from diffusionkit_amd.pipeline import DiffusionPipeline
+    f = load("sd3_full_late")
+    c = fx.SD3_FULL_LATE
+    packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True)}
+    pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
+    check_forced("sd3_full_late", f, forced_steps(pipe, c, dev), "sd3_full_late")
 
 
 def test_eight_seeds_one_step_loop_equal_single_runs(dev):
@@ -327,7 +397,7 @@ def test_eight_seeds_one_step_loop_equal_single_runs(dev):
         lat1, _ = pipe.denoise_latents(text, pooled, num_steps=2, cfg_weight=0.0, latent_size=(128, 128), seed=sd)
         worst = max(worst, rel_l2(lat1[0].cpu(), lat8[i].cpu()))
     print(f"[fullsize] 8 seeds in one step loop vs single runs: worst rel-L2 {worst:.3e}")
-    assert worst <= 1e-2
+    assert worst <= 4e-3  # measured 2.5e-3 (the batched GEMMs pick other tile heights)
 
 
 def test_vae_decode_batch8_equals_single_decodes(dev):
