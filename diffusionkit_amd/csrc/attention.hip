@@ -15,7 +15,8 @@
 // r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
 #include "dk_kernels.h"
 
-extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only)
+extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only);
+                            // 5 / 6 = dk_attn5 with 4 / 8 waves (two query blocks per wave, D = 64 only)
 
 // Hand-off workspace of the balanced form of dk_attn3_fwd_kernel for the launches this host thread enqueues (an engine call sets
 // it to its own engine's region, dk_attention_set_workspace to a caller's buffer; null = plain grids only)
@@ -48,7 +49,11 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
     case 9:  // phase-alternating kernel (attention4.hip); D = 128 only
       rc = p.D == 128 ? dk_launch_attention4(p, stream) : dk_launch_attention2(p, 4, stream);
       break;
-    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 7: pipelined kernel, 9: phase-alternating kernel)");
+    case 5:  // two query blocks per wave (attention5.hip); D = 64 only
+    case 6:
+      rc = p.D == 64 ? dk_launch_attention5(p, mode == 5 ? 4 : 8, stream) : dk_launch_attention2(p, 4, stream);
+      break;
+    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 5 / 6: two query blocks per wave, 7: pipelined kernel, 9: phase-alternating kernel)");
   }
   dk_prof_end(stream);
   if (rc) return rc;
