@@ -5,6 +5,8 @@ the 1/19 sample `bench.py`'s cpu_baseline takes of the same step (1 double + 2 s
 applies is a measured statement.  Test infrastructure: the oracle is the checker, never the product path.
 
     python scripts/cpu_flux_step.py [threads]      ->  profiles/r04_cpu_flux_step.log (copy of stdout)
+Run it ALONE on the box (nothing else on the host cores or the GPU): round 4's first run shared the host with pytest's weight
+threads and measured 250 s against 166 s extrapolated.
 """
 import os
 import sys
@@ -20,14 +22,21 @@ from diffusionkit_amd.weights import synth_mmdit_weights  # noqa: E402
 from oracle.mmdit import OracleMMDiT, Prec, embed_dtype  # noqa: E402
 
 
-class LazyFloat(dict):
-    """bf16 weight dict that hands out fp32 copies on access (24 GB instead of 48 GB of host memory)"""
-
-    def __getitem__(self, k):
-        return dict.__getitem__(self, k).float()
-
-    def get(self, k, default=None):
-        return self[k] if k in self else default
+def aliased_full_weights(cfg, scfg, f):
+    """the weight dict of the full model whose block i shares the tensors of block i % (sample depth) of the sample's weight set:
+    the arithmetic (and its time) is that of the full model, the 12 B-parameter draw (100 s, 48 GB in fp32) is not needed -- a
+    step's duration does not depend on the weight values"""
+    import re
+    w = {k: v.float() for k, v in synth_mmdit_weights(scfg, seed=1).items()}
+    full = dict(w)
+    for kind, depth, sdepth in (("multimodal_transformer_blocks", cfg.depth_multimodal, scfg.depth_multimodal),
+                                ("unified_transformer_blocks", cfg.depth_unified, scfg.depth_unified)):
+        for i in range(sdepth, depth):
+            for k, v in w.items():
+                m = re.match(rf"{kind}\.(\d+)\.(.*)", k)
+                if m and int(m.group(1)) == i % sdepth:
+                    full[f"{kind}.{i}.{m.group(2)}"] = v
+    return full
 
 
 def main():
@@ -42,9 +51,8 @@ def main():
     cb = bench.cpu_baseline(wl, threads=threads)
     print(f"bench.py cpu_baseline (sample, {time.perf_counter() - t0:.0f} s incl. weight draw): {cb['value']:.5f} images/s, {cb['cpu_s_per_step']} s per step", flush=True)
     print("  " + cb["sample"], flush=True)
-    t0 = time.perf_counter()
-    w = LazyFloat(synth_mmdit_weights(cfg, seed=1))
-    print(f"full weight set drawn in {time.perf_counter() - t0:.0f} s", flush=True)
+    scfg, f = bench.cpu_sample_config(cfg)
+    w = aliased_full_weights(cfg, scfg, f)
     g = torch.Generator().manual_seed(0)
     text = torch.randn(1, S_t, cfg.token_level_text_embed_dim, generator=g)
     pooled = torch.randn(1, cfg.pooled_text_embed_dim, generator=g)
@@ -55,7 +63,7 @@ def main():
     model(lat, text, 1000.0)
     t_step = time.perf_counter() - t0
     fl = bench.mmdit_step_flops(cfg, S_t, S_i, 1)
-    print(f"ONE FULL STEP (57 blocks, fp32 weights converted from bf16 per use): {t_step:.1f} s = {fl / 1e12:.2f} TFLOP at {fl / t_step / 1e9:.0f} GFLOP/s", flush=True)
+    print(f"ONE FULL STEP (57 blocks; block i runs on the tensors of sample block i mod 1 / 2: same arithmetic, no 12 B-parameter draw): {t_step:.1f} s = {fl / 1e12:.2f} TFLOP at {fl / t_step / 1e9:.0f} GFLOP/s", flush=True)
     print(f"sample x 19 = {cb['cpu_s_per_step']} s  ->  ratio full / extrapolated = {t_step / cb['cpu_s_per_step']:.3f}", flush=True)
     img_s = 4 * t_step + (cb["cpu_s_per_image"] - 4 * cb["cpu_s_per_step"])
     print(f"image (4 measured-rate steps + the sample's decode time): {img_s:.0f} s = {1.0 / img_s:.5f} images/s on {threads} threads of {cores} cores", flush=True)

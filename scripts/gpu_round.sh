@@ -8,7 +8,7 @@
 #   tests            pytest -m gpu (with -s: the full-size parity lines land in pytest.log)
 #   smoke            __graft_entry__.smoke()
 #   micro            scripts/microbench.py
-#   cpustep          scripts/cpu_flux_step.py in the BACKGROUND (host cores only; joined at the end) -> cpu_flux_step.log
+#   cpustep          scripts/cpu_flux_step.py, ALONE (round 4's first run shared the host with pytest: 250 s instead of ~170) -> cpu_flux_step.log
 #   bench[:name]     python bench.py $BENCH_<name> (default line when no name)          -> bench_<name>.json
 #   prof[:name]      rocprofv3 --kernel-trace --stats over bench.py $BENCH_<name> $PROF_TAIL -> kernel_stats_<name>.md
 #   pmc[:name]       FETCH_SIZE / WRITE_SIZE / SQ passes (separate runs, kernel-trace only)  -> pmc_traffic_<name>.log, pmc_sq_<name>.log
@@ -32,7 +32,6 @@ export TMPDIR=/tmp PYTHONUNBUFFERED=1
 : "${PROF_TAIL:=--no-cpu-baseline --no-roofline --no-other-configs}"
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
 bench_args() { local v="BENCH_$1"; echo "${!v}"; }
-CPU_PID=""
 for ST in $STAGES; do
   KIND=${ST%%:*}; NAME=${ST#*:}; [ "$NAME" = "$ST" ] && NAME=flux
   T0=$(date +%s)
@@ -45,8 +44,7 @@ for ST in $STAGES; do
     micro)
       timeout 600 python scripts/microbench.py > $OUT/micro.log 2>&1; echo "micro exit $?" >> $OUT/micro.log; cat $OUT/micro.log ;;
     cpustep)
-      (timeout 900 python scripts/cpu_flux_step.py > $OUT/cpu_flux_step.log 2>&1; echo "cpustep exit $?" >> $OUT/cpu_flux_step.log) &
-      CPU_PID=$! ;;
+      timeout 900 python scripts/cpu_flux_step.py > $OUT/cpu_flux_step.log 2>&1; echo "cpustep exit $?" >> $OUT/cpu_flux_step.log; cat $OUT/cpu_flux_step.log ;;
     bench)
       timeout 1200 python bench.py --gpus 1 $(bench_args $NAME) > $OUT/bench_$NAME.json 2> $OUT/bench_$NAME.err; echo "bench $NAME exit $?"
       python scripts/bench_line.py $OUT/bench_$NAME.json ;;
@@ -80,5 +78,4 @@ for ST in $STAGES; do
   esac
   echo "[stage $ST: $(( $(date +%s) - T0 )) s]"
 done
-if [ -n "$CPU_PID" ]; then wait $CPU_PID; cat $OUT/cpu_flux_step.log; fi
 ls -la $OUT

@@ -36,7 +36,8 @@ def main():
     print("| kernel | launches | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM bytes/launch (2*fetch + write) |\n|---|---|---|---|---|")
     for k, n, f, w, b in rows[:14]:
         print(f"| `{k[:70]}` | {n} | {f:.0f} | {w:.0f} | {b:.4g} |")
-    dom = [r for r in rows if "gemm256v3" in r[0]] or [r for r in rows if "gemm" in r[0]]
+    # the dominant GEMM kernel of the run = the GEMM kernel with the most bytes over all its launches (rows are sorted that way)
+    dom = [r for r in rows if "gemm256" in r[0]] or [r for r in rows if "gemm" in r[0]]
     if dom:
         k, n, f, w, b = dom[0]
         out = {"kernel": k, "launches": n, "fetch_kib_per_launch_raw": f, "write_kib_per_launch": w, "hbm_bytes_per_launch": b,

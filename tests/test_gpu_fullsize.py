@@ -337,7 +337,7 @@ FORCED_TOL = {
     # case: (min PSNR dB, max rel-L2) of every step's Euler direction d_i against the fp32 oracle's
     "flux_dev_full": (48.0, 1.6e-2),
     "flux_dev_full_fp8": (30.0, 1.3e-1),
-    "sd3_full_late": (45.0, 2.6e-2),   # CFG 5 amplifies: the bf16-emulating oracle sits at 47.6-49.2 dB / 1.64e-2-1.75e-2
+    "sd3_full_late": (46.0, 2.5e-2),   # measured 47.98-49.55 dB / 1.58e-2-1.69e-2 (CFG 5 amplifies; bf16-emulating oracle 47.6-49.2 dB / 1.64e-2-1.75e-2)
 }
 
 
