@@ -13,6 +13,7 @@
 #   prof[:name]      rocprofv3 --kernel-trace --stats over bench.py $BENCH_<name> $PROF_TAIL -> kernel_stats_<name>.md
 #   pmc[:name]       FETCH_SIZE / WRITE_SIZE / SQ passes (separate runs, kernel-trace only)  -> pmc_traffic_<name>.log, pmc_sq_<name>.log
 #   run:<script>     any other script of scripts/ (python or shell), logged                  -> <script>.log
+#   custom[:name]    eval "$CUSTOM_<name>" (a shell command line from the environment), logged -> custom_<name>.log
 # named bench argument sets (override through the environment):
 #   BENCH_flux="--steps 3 --warmup 1"   BENCH_sd3="--workload sd3-medium-1024 --steps 2 --warmup 1"
 #   BENCH_fp8="--workload flux-dev-1024 --fp8 --steps 2 --warmup 1"   BENCH_driver="--steps 20 --warmup 5"
@@ -74,6 +75,9 @@ for ST in $STAGES; do
         *) timeout 900 bash scripts/$NAME $OUT > $OUT/${NAME%.*}.log 2>&1 ;;
       esac
       echo "run $NAME exit $?"; tail -n 25 $OUT/${NAME%.*}.log ;;
+    custom)
+      V="CUSTOM_$NAME"; echo "+ ${!V}" > $OUT/custom_$NAME.log
+      ( eval "timeout 1200 ${!V}" ) >> $OUT/custom_$NAME.log 2>&1; echo "custom $NAME exit $?"; tail -n 40 $OUT/custom_$NAME.log ;;
     *) echo "unknown stage $ST" ;;
   esac
   echo "[stage $ST: $(( $(date +%s) - T0 )) s]"

@@ -388,7 +388,7 @@ CASES = {"flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,
          "flux_blocks": make_flux_blocks,
-         "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", False),
+         "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", True),
          "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True)}
 
 if __name__ == "__main__":
