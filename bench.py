@@ -360,6 +360,68 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
     return res
 
 
+def dry_run(args):
+    """--dry-run: see the flag's help.  Same statements as main() / run_workload() wherever they do not touch the device."""
+    import torch
+    import torch.distributed as dist
+    from diffusionkit_amd import dist as dk
+    from diffusionkit_amd.config import tiny_flux, tiny_vae
+    from diffusionkit_amd.weights import pack_mmdit, pack_vae, synth_mmdit_weights, synth_vae_weights
+    rank, local_rank, world = dk.init_distributed("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    B = (8 if world > 1 else 1) if args.batch == "auto" else int(args.batch)
+    cfg, vcfg = tiny_flux(), tiny_vae()
+    packed = None
+    if rank == 0:
+        packed = {"mmdit/" + k: v for k, v in pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=1234), "cpu").items()}
+        packed.update({"vae/" + k: v for k, v in pack_vae(vcfg, synth_vae_weights(vcfg, seed=1235), "cpu").items()})
+    t0 = time.perf_counter()
+    packed = dk.broadcast_weights(packed, "cpu", src=0)
+    t_bcast = time.perf_counter() - t0
+    blob_bytes = sum(v.numel() * v.element_size() for v in packed.values())
+    seeds = dk.shard_seeds(list(range(world * B)), rank, world)  # configs[4]: rank r denoises seeds 8r .. 8r + 7 in one batched step loop
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def one_image(i):
+        time.sleep(0.01 * (1 + rank))  # the slowest rank sets the time: MAX over ranks below
+
+    for i in range(args.warmup):
+        one_image(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_image(i)
+    own = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [args.steps * B / own]
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        mine = torch.tensor([args.steps * B / own], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"images/sec (whole node) {WORKLOAD_NAMES[args.workload]}", "dry_run": True,
+            "value": round(world * args.steps * B / elapsed, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none (dry run: device work replaced by a sleep)", "data": "none",
+            "config": {"workload": f"dry run of the control path: batch {B} images per rank per step, seeds of rank 0: {seeds}",
+                       "parallelism": f"dp{world} (independent images, weight broadcast at load)"},
+            "world": world, "collective_backend": "gloo" if world > 1 else None, "weight_bcast_s": round(t_bcast, 3),
+            "weight_blob_gb": round(blob_bytes / 1e9, 6), "per_rank_images_per_s": [round(v, 4) for v in per_rank],
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,10 +445,17 @@ def main():
                          "fp8 weights) that the default single-GPU headline run appends as `other_configs`")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="dk_tune_set knob for A/B runs, e.g. --tune gemm_mf=8 (default kernels otherwise)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the multi-rank CONTROL path of this script on the host through gloo (rank spawn, rendezvous on 127.0.0.1, "
+                         "--batch auto, packed-weight broadcast of the tiny model, barriers, MAX-over-ranks timing, per-rank gather, the JSON line) "
+                         "with the device work replaced by a sleep -- what tests/test_dist_cpu.py runs so that the first 8-GPU launch is not the "
+                         "first time this code runs.  The line carries \"dry_run\": true and no roofline.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist

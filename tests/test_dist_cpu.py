@@ -76,3 +76,26 @@ def test_broadcast_and_gather_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+def test_bench_multi_rank_control_path_dry_run():
+    """`bench.py --gpus 2 --batch auto --dry-run`: the script's own rank spawn, rendezvous, weight broadcast, barriers, MAX over ranks
+    and per-rank gather through gloo on the host (the first 8-GPU run must not be the first run of this code)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "auto", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["world"] == 2 and d["collective_backend"] == "gloo" and d["scaling"] == "weak"
+    assert "batch 8 images per rank" in d["config"]["workload"] and d["config"]["parallelism"].startswith("dp2")
+    assert len(d["per_rank_images_per_s"]) == 2 and d["per_rank_images_per_s"][0] > d["per_rank_images_per_s"][1]  # rank 1 sleeps longer
+    # value = all ranks' images / the slowest rank's time (MAX over ranks), not the sum of the per-rank rates
+    assert abs(d["value"] - 2 * 3 * 8 / (d["ms_per_step"] * 3e-3)) <= 1e-2 * d["value"]
+    assert d["value"] <= 2 * d["per_rank_images_per_s"][1] * 1.02
+    assert d["weight_blob_gb"] > 0
