@@ -13,10 +13,12 @@
 // waves of a SIMD in opposite matrix / vector phases; D = 128; the default on long sequences: +12 % over attention3 on the FLUX
 // shapes in isolation, 815 -> 932 TF inside the model).  Round 3 pruned the variants whose A/B is settled (profiles/archive/r01_attention_lab.md,
 // r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
+// Round 4: a D = 64 form with two query blocks per wave (half the LDS bytes per MFMA) measured +1.3 % isolated and +0.4 % / -0.9 % inside
+// SD3-medium / SD3.5-large -- the lean kernel at D = 64 is bound by VALU issue, not by the LDS (profiles/r04_sd3_pmc.md,
+// profiles/lab_kernels/attention5_two_query_blocks.hip); not built.
 #include "dk_kernels.h"
 
-extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only);
-                            // 5 / 6 = dk_attn5 with 4 / 8 waves (two query blocks per wave, D = 64 only)
+extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only)
 
 // Hand-off workspace of the balanced form of dk_attn3_fwd_kernel for the launches this host thread enqueues (an engine call sets
 // it to its own engine's region, dk_attention_set_workspace to a caller's buffer; null = plain grids only)
@@ -49,11 +51,7 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
     case 9:  // phase-alternating kernel (attention4.hip); D = 128 only
       rc = p.D == 128 ? dk_launch_attention4(p, stream) : dk_launch_attention2(p, 4, stream);
       break;
-    case 5:  // two query blocks per wave (attention5.hip); D = 64 only
-    case 6:
-      rc = p.D == 64 ? dk_launch_attention5(p, mode == 5 ? 4 : 8, stream) : dk_launch_attention2(p, 4, stream);
-      break;
-    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 5 / 6: two query blocks per wave, 7: pipelined kernel, 9: phase-alternating kernel)");
+    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 7: pipelined kernel, 9: phase-alternating kernel)");
   }
   dk_prof_end(stream);
   if (rc) return rc;

@@ -173,7 +173,6 @@ struct Attn512Params {
   int T, Tp, B, ld, ldo;
   float scale;
 };
-int dk_launch_attention5(const AttnParams& p, int waves, hipStream_t stream);  // attention5.hip (D = 64: two 32-query blocks per wave; no score bias)
 int dk_launch_attention512(const Attn512Params& p, hipStream_t stream);
 
 // ---- text-conditioning kernels (text_ops.hip) ---------------------------------------------------

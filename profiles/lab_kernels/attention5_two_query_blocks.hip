@@ -1,3 +1,9 @@
+// LAB KERNEL, not part of libdk_hip.so (round 4).  Built, parity-tested on the GPU (oracle: rel-L2 < 6e-3 on nine shapes up to
+// B 2 x S 4685; against the lean kernel: max 2.4e-4 = rare bf16 flips of a probability) and measured: +1.3 % on the SD3-medium
+// shape, +3 % on SD3.5-large, +17 % at B 1 (grid rounds), -13 % at S = 1613 in isolation (profiles/r04_attention_d64_two_blocks.log);
+// inside the model +0.4 % (SD3-medium) / -0.9 % (SD3.5-large) (profiles/r04_attention_d64_in_model.log).  The hypothesis it tested --
+// the D = 64 kernel is bound by LDS bytes per MFMA -- is refuted: halving them changes nothing; DESIGN.md section 7.
+// To rebuild: copy to diffusionkit_amd/csrc/attention5.hip, add it to the Makefile (flags of attention4.o) and a case to attention.hip.
 // Joint text/image attention forward for head_dim 64 with TWO 32-query blocks per wave (dk_attn5_fwd_kernel): the SD3 family
 // (mmdit.py:608-625,643; 24 / 38 heads of 64 -- config.py:19-74).
 //

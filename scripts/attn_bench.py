@@ -13,7 +13,7 @@ shapes = [("flux B1 S4352 D128", 1, 24, 4352, 128), ("flux-dev B1 S4608 D128", 1
           ("flux B4", 4, 24, 4352, 128)]
 modes = sys.argv[1:] or ["7", "9", "4"]  # "7b": mode 7 in its balanced form (one workgroup per CU, hand-off workspace)
 ws = ops.attention_workspace(dev)
-if os.environ.get("ATTN_SHAPES") == "d64":  # the SD3 family: modes 4 (lean), 5 / 6 (two query blocks per wave, 4 / 8 waves)
+if os.environ.get("ATTN_SHAPES") == "d64":  # the SD3 family (round 4: lean kernel against the lab build with profiles/lab_kernels/attention5_two_query_blocks.hip, modes 5 / 6)
     shapes = [("sd3 B2 S4685 H24 D64", 2, 24, 4096 + 589, 64), ("sd3.5-large B2 S4685 H38 D64", 2, 38, 4096 + 589, 64),
               ("sd3 512^2 B2 S1613 H24 D64", 2, 24, 1024 + 589, 64), ("sd3 B1 S4685 H24 D64", 1, 24, 4096 + 589, 64)]
 elif os.environ.get("ATTN_SHAPES"):

@@ -410,59 +410,6 @@ def test_attention_kernel_variants(dev, mode, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
-@pytest.mark.parametrize("mode", [5, 6])
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 2, 100), (2, 3, 700), (2, 2, 589 + 64), (1, 3, 256), (1, 2, 257), (1, 2, 511), (2, 2, 1100),
-                                   (2, 4, 4096 + 589)])  # the last: SD3-medium 1024^2 (B 2, S 4685: 73.2 key tiles, ragged query blocks)
-def test_attention_two_query_blocks_per_wave(dev, mode, B, H, S):
-    """dk_attn5_fwd_kernel (D = 64, round 4): every wave carries two 32-query blocks, 4 waves (mode 5, 256 queries per workgroup)
-    or 8 (mode 6, 512) -- against the oracle, and against the lean kernel: per query the same tiles, the same order of every sum and
-    the same rescale decisions (the vote is per 32-query block in both)."""
-    from diffusionkit_amd import ops
-    D = 64
-    h = H * D
-    qkv = randn(B, S, 3 * h, seed=32)
-    try:
-        ops.tune("attn", mode)
-        y = ops.attention(g(qkv, dev), H, D)
-        ops.tune("attn", 4)
-        y4 = ops.attention(g(qkv, dev), H, D)
-    finally:
-        ops.tune("attn", -1)
-    if B * H * S * S <= 2 * 4 * 1100 * 1100:
-        q, k, v = (qkv[..., i * h:(i + 1) * h].reshape(B, S, H, D).transpose(1, 2) for i in range(3))
-    else:  # oracle on one image and two heads
-        q, k, v = (qkv[:1, :, i * h:i * h + 2 * D].reshape(1, S, 2, D).transpose(1, 2) for i in range(3))
-        y, y4 = y[:1, :, :2 * D], y4[:1, :, :2 * D]
-    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(y.shape)
-    assert rel_l2(ref, y.float()) < 6e-3
-    assert max_abs(ref, y.float()) < 0.03
-    # (the two kernels are compiled with different flags -- attention2.o may evaluate s * c - m * c as a packed multiply + subtract
-    #  where attention5.o uses a fused multiply-add: one fp32 ulp in an exponent, a rare bf16 flip of a probability; measured over
-    #  74 key tiles: max 2.4e-4, bit-identical up to 17 tiles)
-    assert max_abs(y4.float(), y.float()) <= 1e-3 and float((y != y4).float().mean()) < 1e-2
-
-
-def test_attention_two_query_blocks_spiked_key(dev):
-    """the rescale path of dk_attn5_fwd_kernel: a key that dominates late for ONE query of the wave's second block (the vote is per
-    block: the first block must not rescale); fp64 reference"""
-    from diffusionkit_amd import ops
-    B, H, S, D = 1, 1, 320, 64
-    h = H * D
-    qkv = randn(B, S, 3 * h, seed=31, scale=0.5)
-    qkv[0, 250, h:2 * h] = bf16r(qkv[0, 39, :h] * 9.0)  # key 250 aligned with query 39 (block 1 of wave 0)
-    q, k, v = (qkv[..., i * h:(i + 1) * h].double() for i in range(3))
-    p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
-    ref = (p @ v[0])[None]
-    assert float(p[39, 250]) > 0.9
-    for mode in (4, 5, 6):
-        try:
-            ops.tune("attn", mode)
-            y = ops.attention(g(qkv, dev), H, D)
-        finally:
-            ops.tune("attn", -1)
-        assert rel_l2(ref, y.float()) < 6e-3, mode
-
-
 @pytest.mark.parametrize("B,H,S,qfuse", [(1, 24, 4352, False),   # FLUX: 408 tasks of 68 tiles on 256 CUs, every workgroup but the last splits a task
                                          (1, 24, 4352 - 37, False),  # ragged tail tile inside a tail segment
                                          (2, 17, 3000, False),     # 408 tasks again, two images
