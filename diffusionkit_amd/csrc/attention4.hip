@@ -42,12 +42,6 @@
 #define DK4_TRACE 0
 #endif
 
-// lab (round 4): where the two K and the two V slots sit in the LDS.  0: K0 K1 V0 V1 (16 KiB apart, shipped); 1: K0 V0 K1 V1;
-// 2: K0 . V0 . K1 . V1 (32 KiB apart, 112 KiB of LDS) -- the s_memtime traces show the P.V half of every EVEN tile's M phase
-// 300-1000 cycles slower than the odd tiles' (profiles/r03_attention_trace_final.log), with a code path that is symmetric in the parity
-#ifndef DK4_LAYOUT
-#define DK4_LAYOUT 0
-#endif
 struct Attn4Cfg {
   static constexpr int D = 128, NW = 8;
   static constexpr int KV = 64;
@@ -58,9 +52,7 @@ struct Attn4Cfg {
   static constexpr int NCH = NCHUNK / NT;    // per thread
   static constexpr int CPR = D / 8;
   static constexpr int QB = NW * 32;
-  static constexpr int K_SLOT(int s) { return (DK4_LAYOUT == 0 ? s : DK4_LAYOUT == 1 ? 2 * s : 4 * s) * TILE_BYTES; }
-  static constexpr int V_SLOT(int s) { return (DK4_LAYOUT == 0 ? 2 + s : DK4_LAYOUT == 1 ? 2 * s + 1 : 4 * s + 2) * TILE_BYTES; }
-  static constexpr int LDS_BYTES = (DK4_LAYOUT == 2 ? 7 : 4) * TILE_BYTES;  // K[2] V[2]
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;  // K[2] V[2]
 };
 
 typedef __attribute__((address_space(3))) char lds_char4;
@@ -80,6 +72,7 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char4*)smem != 0u) __builtin_trap();  // LDS addressed from 0: offsets fold into instruction immediates
   lds_char4* const lds = (lds_char4*)0;
+  constexpr int K_OFF = 0, V_OFF = 2 * C::TILE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,8 +105,8 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
     const unsigned vs = (unsigned)((c8 >> 1) * 2048 + (kl ^ ((((c8 >> 1) & 1) << 2) | ((c8 >> 1) & 3))) * 32 + (c8 & 1) * 16);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      ks_off[par][i] = (unsigned)(((par + 1 + grp) & 1) ? C::K_SLOT(1) : C::K_SLOT(0)) + ks;  // V(j) stores K(j + 1 + grp)
-      vs_off[par][i] = (unsigned)(((par + grp) & 1) ? C::V_SLOT(1) : C::V_SLOT(0)) + vs;      // ... and V(j + grp)
+      ks_off[par][i] = K_OFF + (unsigned)(((par + 1 + grp) & 1) * C::TILE_BYTES) + ks;  // V(j) stores K(j + 1 + grp)
+      vs_off[par][i] = V_OFF + (unsigned)(((par + grp) & 1) * C::TILE_BYTES) + vs;      // ... and V(j + grp)
     }
   }
   const unsigned kr_base = (unsigned)(l31 * C::ROWB + ((hi ^ (l31 & 15)) << 4));
@@ -212,13 +205,13 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
     asm volatile("" : "+v"(fr[(I) & 7]));                                                                                                      \
   } else if ((I) < 16) {                                                                                                                              \
     const int dt_ = (I) & 3, n_ = (I) >> 2;                                                                                                    \
-    const int imm_ = C::V_SLOT((SLOT) ^ 1) + dt_ * 4096 + (32 * (n_ >> 1) + 16 * (n_ & 1)) * 32;                                \
+    const int imm_ = V_OFF + ((SLOT) ^ 1) * C::TILE_BYTES + dt_ * 4096 + (32 * (n_ >> 1) + 16 * (n_ & 1)) * 32;                                \
     const s16x4 vh0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm_ + vr_off[dt_ & 1]));       \
     const s16x4 vh1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + imm_ + 256 + vr_off[dt_ & 1])); \
     fr[(I) & 7] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vh0_, vh1_, 0, 1, 2, 3, 4, 5, 6, 7));                                      \
   } else {                                                                                                                                     \
     const int kk_ = ((I) - 16) >> 1, half_ = (I) & 1;                                                                                          \
-    fr[(I) & 7] = *(const __attribute__((address_space(3))) bf16x8*)(lds + C::K_SLOT(SLOT) + half_ * 32 * C::ROWB + (kr_base ^ (unsigned)(kk_ << 5))); \
+    fr[(I) & 7] = *(const __attribute__((address_space(3))) bf16x8*)(lds + K_OFF + (SLOT) * C::TILE_BYTES + half_ * 32 * C::ROWB + (kr_base ^ (unsigned)(kk_ << 5))); \
   }
 #define DK4_M1(I)                                                                                                     \
   if (DK4_ABL & 32) {                                                                                                 \
@@ -273,8 +266,8 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
 #pragma unroll
   for (int i = 0; i < C::NCH; ++i) {
     // K(0) -> slot 0 for both groups (ks_off carries the steady-state slot, which differs per group: take the slot bits out)
-    const unsigned off = ks_off[0][i] & (unsigned)(C::TILE_BYTES - 1);
-    *(__attribute__((address_space(3))) u32x4*)(lds + C::K_SLOT(0) + off) = kreg[i];
+    const unsigned off = (ks_off[0][i] - K_OFF) & (unsigned)(C::TILE_BYTES - 1);
+    *(__attribute__((address_space(3))) u32x4*)(lds + K_OFF + off) = kreg[i];
   }
   if (grp == 1) {
     if (nt > 1) {
