@@ -37,7 +37,7 @@
 #ifndef DK4_ABL
 #define DK4_ABL 0
 #endif
-// lab only (scripts/attn_trace.py): waves 0 and 4 of workgroup 0 stamp s_memtime at the phase boundaries of tiles 20..27 into p.bal_ws
+// lab only (scripts/attn_trace.py): the eight waves of workgroup 0 stamp s_memtime at the phase boundaries of tiles 20..27 into p.bal_ws
 #ifndef DK4_TRACE
 #define DK4_TRACE 0
 #endif
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale * 1.44269504088896340736f;  // p = 2^(s*c - m*c)
   const float thr = DK4_RESCALE_THR / p.scale;         // threshold on the raw scores
-  const bool trace_on = DK4_TRACE && blockIdx.x == 0 && (wave & 3) == 0 && p.bal_ws != nullptr;
-  unsigned long long* const trace_buf = (unsigned long long*)p.bal_ws + (wave >> 2) * 64;  // 8 tiles x 6 stamps per group
+  const bool trace_on = DK4_TRACE && blockIdx.x == 0 && p.bal_ws != nullptr;
+  unsigned long long* const trace_buf = (unsigned long long*)p.bal_ws + wave * 64;  // 8 tiles x 6 stamps per wave
   bf16x8 pf[4];
   f32x16 s0, s1;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -1,5 +1,6 @@
 """lab: phase timeline of the phase-alternating attention kernel (a -DDK4_TRACE=1 build through DK_HIP_LIB, scripts/build_attn_abl.sh
-K=4): s_memtime stamps of waves 0 (group A) and 4 (group B) of workgroup 0 around the phases of tiles 20..27 on the FLUX shape.
+K=4): s_memtime stamps of all eight waves of workgroup 0 around the phases of tiles 20..27 on the FLUX shape (round 4: every wave, to see which
+wave a barrier waits for).
 Every stamp costs ~70 cycles (scalar memory round trip), the split of the M phase another LDS latency."""
 import os
 import sys
@@ -18,13 +19,14 @@ for _ in range(3):
     ws.zero_()
     y = ops.attention(qkv, H, D, workspace=ws)
 torch.cuda.synchronize()
-t = ws[:1024].view(torch.int64).cpu().view(2, 64)[:, :48].reshape(2, 8, 6)
-t0 = int(t[0, 0, 0])
-for g in range(2):
-    print("group", "AB"[g], "(wave", 4 * g, "of workgroup 0; s_memtime ticks)")
-    for j in range(8):
-        row = [int(t[g, j, k]) - t0 for k in range(6)]
-        nxt = int(t[g, j + 1, 0]) - t0 if j < 7 else None
-        print(f"  tile {20 + j} @ {row[0]:6d}: load issue {row[1] - row[0]:5d}  M: P.V {row[2] - row[1]:5d}  QK {row[3] - row[2]:5d}  barrier {row[4] - row[3]:5d}  V {row[5] - row[4]:5d}" +
-              (f"  barrier {nxt - row[5]:5d}  tile {nxt - row[0]:5d}" if nxt is not None else ""))
+t = ws[:4096].view(torch.int64).cpu().view(8, 64)[:, :48].reshape(8, 8, 6)
+t0 = int(t[:, 0, 0].min())
+print("s_memtime ticks; per wave and tile: start | M phase (P.V + QK) | wait at barrier 1 | V phase | wait at barrier 2   (waves 0-3: group A, 4-7: group B; wave w and w + 4 share a SIMD)")
+for j in range(8):
+    print(f"tile {20 + j}")
+    for w in range(8):
+        r = [int(t[w, j, k]) - t0 for k in range(6)]
+        nxt = int(t[w, j + 1, 0]) - t0 if j < 7 else None
+        print(f"  wave {w}: @{r[0]:6d}  M {r[3] - r[0]:5d} (P.V {r[2] - r[1]:5d}, QK {r[3] - r[2]:5d})  wait {r[4] - r[3]:5d}  V {r[5] - r[4]:5d}" +
+              (f"  wait {nxt - r[5]:5d}  period {nxt - r[0]:5d}" if nxt is not None else ""))
 ws.zero_()
