@@ -374,6 +374,8 @@ def test_latent_sample(dev):
 # ---- attention ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 128, 128), (1, 3, 200, 128), (2, 4, 333, 64), (1, 24, 1088, 128),
                                      (2, 24, 589 + 64, 64),
+                                     # SD3-medium 1024^2 (BASELINE configs[2]): B 2, S = 4096 + 589 = 4685 -- 73.2 key tiles, ragged last query block
+                                     (2, 4, 4096 + 589, 64),
                                      # the automatic choice at D = 128, S >= 2048 (phase-alternating kernel): ragged last key tile
                                      # and last query block, two images; a whole number of both
                                      (2, 3, 2048 + 17, 128), (1, 2, 2304, 128)])
