@@ -81,9 +81,24 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const int tile = f8_xcd_contiguous(blockIdx.x, tiles_a + tiles_b);
   const bool second = tile >= tiles_a;
   const GemmF8Params& p = second ? pb : pa;
+  // the twelve ints of the parameter block that prologue AND tail use, selected once into scalars: left as `p.x` the compiler kept a copy of
+  // both blocks' M .. c_seg_len in SCRATCH and read them back with dynamically indexed scratch_load_dword (105 sites, vector registers,
+  // memory latency at the head of every tail) -- round 4
+  const int p_M = second ? pb.M : pa.M;
+  const int p_N = second ? pb.N : pa.N;
+  const int p_K = second ? pb.K : pa.K;
+  const int p_lda = second ? pb.lda : pa.lda;
+  const int p_ldw = second ? pb.ldw : pa.ldw;
+  const int p_ldc = second ? pb.ldc : pa.ldc;
+  const int p_ldr = second ? pb.ldr : pa.ldr;
+  const int p_a_seg_len = second ? pb.a_seg_len : pa.a_seg_len;
+  const int p_a_seg_stride = second ? pb.a_seg_stride : pa.a_seg_stride;
+  const int p_a_row0 = second ? pb.a_row0 : pa.a_row0;
+  const int p_sa_nblk = second ? pb.sa_nblk : pa.sa_nblk;
+  const int p_c_seg_len = second ? pb.c_seg_len : pa.c_seg_len;
   const int tl = second ? tile - tiles_a : tile;
-  const int nk = p.K / BKB;
-  const int nbm = (p.M + T256 - 1) / T256, nbn = p.N / T256;
+  const int nk = p_K / BKB;
+  const int nbm = (p_M + T256 - 1) / T256, nbn = p_N / T256;
 
   // lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), read j = position (4 j + q) ^ swz(row)
   unsigned offk[2];
@@ -107,17 +122,17 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);  // = (lane & 7) ^ swz(row), row = wave * 16 + j * 8 + srow
-    lw[j] = (unsigned)srow * (unsigned)p.ldw + chunk * 16;
+    lw[j] = (unsigned)srow * (unsigned)p_ldw + chunk * 16;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const int m = min(m0 + hh * 128 + wave * 16 + j * 8 + srow, p.M - 1);
-      const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
-      la[hh][j] = phys * (unsigned)p.lda + chunk * 16;
+      const int m = min(m0 + hh * 128 + wave * 16 + j * 8 + srow, p_M - 1);
+      const unsigned phys = (unsigned)((m / p_a_seg_len) * p_a_seg_stride + (m % p_a_seg_len));
+      la[hh][j] = phys * (unsigned)p_lda + chunk * 16;
     }
   }
   const char* gA = (const char*)p.A;
-  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p.ldw;
-  const size_t w128 = (size_t)128 * p.ldw, w8 = (size_t)8 * p.ldw;
+  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p_ldw;
+  const size_t w128 = (size_t)128 * p_ldw, w8 = (size_t)8 * p_ldw;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
   // the four DMA instructions (k: half, j) of one operand of K-tile i; `slot` = byte offset of the ring slot it goes to
@@ -138,10 +153,10 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   // (clamped to the last row block of M: the second wave row of a tile whose rows end at m0 + 128 owns no rows -- its results are
   //  masked -- and must not read scale bytes past the caller's side array)
   const int mrow0 = m0 + wm * 128;
-  const int mrow_sc = min(mrow0, (p.M - 1) & ~127);
-  const unsigned a_blk = (unsigned)(((mrow_sc / p.a_seg_len) * p.a_seg_stride + (mrow_sc % p.a_seg_len) + p.a_row0) >> 7);
+  const int mrow_sc = min(mrow0, (p_M - 1) & ~127);
+  const unsigned a_blk = (unsigned)(((mrow_sc / p_a_seg_len) * p_a_seg_stride + (mrow_sc % p_a_seg_len) + p_a_row0) >> 7);
   const unsigned char* sa_ptr = p.SA + ((size_t)a_blk * 64 + lane) * 8;
-  const size_t sa_step = (size_t)p.sa_nblk * 512;  // bytes between K-tiles
+  const size_t sa_step = (size_t)p_sa_nblk * 512;  // bytes between K-tiles
   u32x2 sa_cur, sa_nxt;
 
   f32x4 acc[4][8];  // [nf][mf]
@@ -334,15 +349,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   // All waves passed the last loop barrier after their final ds_read of live data, so the ring is free.
   const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
   void* const Cb = out2 ? p.C2 : p.C;
-  const int ldcb = out2 ? p.ldc2 : p.ldc;
+  const int ldcb = out2 ? p.ldc2 : p_ldc;
   const int epi = out2 ? p.epi2 : p.epi;
   const bool out_mx8 = out2 ? p.c2_mx8 != 0 : p.c_mx8 != 0;
   const int ncol0 = out2 ? n0 - p.n_split : n0;
   const bool has_res = epi == DK_EPI_GATE_RES || epi == DK_EPI_RES;
   auto inside = [&](int len) { return m0 / len == (m0 + T256 - 1) / len; };
-  const bool fast = m0 + T256 <= p.M && inside(p.c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
+  const bool fast = m0 + T256 <= p_M && inside(p_c_seg_len) && (!has_res || inside(p.r_seg_len)) &&
                     (epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
-  const size_t physC0 = (size_t)((m0 / p.c_seg_len) * p.c_seg_stride + (m0 % p.c_seg_len)) + wm * 128;
+  const size_t physC0 = (size_t)((m0 / p_c_seg_len) * p.c_seg_stride + (m0 % p_c_seg_len)) + wm * 128;
   const size_t physR0 = has_res ? (size_t)((m0 / p.r_seg_len) * p.r_seg_stride + (m0 % p.r_seg_len)) + wm * 128 : 0;
   const bf16_t* gate_row = epi == DK_EPI_GATE_RES ? p.gate + (size_t)(m0 / p.gate_seg_len) * p.gate_stride : nullptr;
   const unsigned reg0 = (unsigned)wave * 16384u;  // this wave's 16 KiB staging image
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
       int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
       if (!FAST) {
         const int ms = mrow0 + rrow;
-        c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
+        c_seg = ms / p_c_seg_len, c_rem = ms % p_c_seg_len;
         if (hres) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
         if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
@@ -441,11 +456,11 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
         bool valid = true;
         if (!FAST) {
-          valid = mrow0 + row < p.M;
+          valid = mrow0 + row < p_M;
           crow = (size_t)c_seg * p.c_seg_stride + c_rem;
           rrow_phys = (size_t)r_seg * p.r_seg_stride + r_rem;
           if (ep == DK_EPI_GATE_RES && valid) unpack8(*(const uint4*)(p.gate + (size_t)g_seg * p.gate_stride + col), gate8);
-          for (c_rem += 16; c_rem >= p.c_seg_len; c_rem -= p.c_seg_len) ++c_seg;
+          for (c_rem += 16; c_rem >= p_c_seg_len; c_rem -= p_c_seg_len) ++c_seg;
           if (hres)
             for (r_rem += 16; r_rem >= p.r_seg_len; r_rem -= p.r_seg_len) ++r_seg;
           if (ep == DK_EPI_GATE_RES)
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
         } else if (hres) {
           uint4 rr = make_uint4(0u, 0u, 0u, 0u);
-          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
+          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p_ldr + col);
           float r8[8];
           unpack8(rr, r8);
           if (ep == DK_EPI_GATE_RES) {
