@@ -80,22 +80,28 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 
   const int tile = f8_xcd_contiguous(blockIdx.x, tiles_a + tiles_b);
   const bool second = tile >= tiles_a;
-  const GemmF8Params& p = second ? pb : pa;
-  // the twelve ints of the parameter block that prologue AND tail use, selected once into scalars: left as `p.x` the compiler kept a copy of
-  // both blocks' M .. c_seg_len in SCRATCH and read them back with dynamically indexed scratch_load_dword (105 sites, vector registers,
-  // memory latency at the head of every tail) -- round 4
-  const int p_M = second ? pb.M : pa.M;
-  const int p_N = second ? pb.N : pa.N;
-  const int p_K = second ? pb.K : pa.K;
-  const int p_lda = second ? pb.lda : pa.lda;
-  const int p_ldw = second ? pb.ldw : pa.ldw;
-  const int p_ldc = second ? pb.ldc : pa.ldc;
-  const int p_ldr = second ? pb.ldr : pa.ldr;
-  const int p_a_seg_len = second ? pb.a_seg_len : pa.a_seg_len;
-  const int p_a_seg_stride = second ? pb.a_seg_stride : pa.a_seg_stride;
-  const int p_a_row0 = second ? pb.a_row0 : pa.a_row0;
-  const int p_sa_nblk = second ? pb.sa_nblk : pa.sa_nblk;
-  const int p_c_seg_len = second ? pb.c_seg_len : pa.c_seg_len;
+  // ONE scalar base into the kernel-argument segment for this tile's parameter block (round 4; gemm256v3.hip).  Written as
+  // `second ? pb : pa` the compiler kept both blocks' M .. c_seg_len in SCRATCH and read them back with dynamically indexed scratch_load_dword
+  // (105 sites, vector registers, memory latency at the head of every prologue and tail) and selected the rest field by field: 106 SGPRs + lane
+  // spills.  Now 72 SGPRs, 232 VGPRs, no scratch: +7-12 % per launch on the FLUX shapes, FLUX.1-dev fp8 44.2 -> 42.7 ms per step
+  // (profiles/r04_gemm_fp8_scalar_params.log, r04_gemm_kernarg_pointer.log).
+  static_assert(sizeof(GemmF8Params) % 8 == 0 && alignof(GemmF8Params) == 8, "pb follows pa without padding");
+  typedef const __attribute__((address_space(4))) GemmF8Params karg_params_t;
+  const __attribute__((address_space(4))) char* kbase = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  karg_params_t& p = *(karg_params_t*)(kbase + (second ? sizeof(GemmF8Params) : 0));
+  // (the twelve ints prologue and tail share, as named scalars)
+  const int p_M = p.M;
+  const int p_N = p.N;
+  const int p_K = p.K;
+  const int p_lda = p.lda;
+  const int p_ldw = p.ldw;
+  const int p_ldc = p.ldc;
+  const int p_ldr = p.ldr;
+  const int p_a_seg_len = p.a_seg_len;
+  const int p_a_seg_stride = p.a_seg_stride;
+  const int p_a_row0 = p.a_row0;
+  const int p_sa_nblk = p.sa_nblk;
+  const int p_c_seg_len = p.c_seg_len;
   const int tl = second ? tile - tiles_a : tile;
   const int nk = p_K / BKB;
   const int nbm = (p_M + T256 - 1) / T256, nbn = p_N / T256;

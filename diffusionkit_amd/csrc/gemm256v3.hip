@@ -157,7 +157,14 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
     }
   }
   const bool second = tile >= tiles_a;
-  const GemmParams& p = second ? pb : pa;
+  // ONE scalar base into the kernel-argument segment for this tile's parameter block (round 4).  Written as `second ? pb : pa` the compiler
+  // loads BOTH blocks and s_cselects field by field (36 selects and 30 SGPRs spilled to VGPR lanes in the prologue, 2039 v_readlane over the
+  // tail's code paths); with a base pointer every field is one s_load at its use: 100-104 -> 82-104 SGPRs, no lane spills, +0.5 % in the model
+  // (profiles/r04_gemm_kernarg_pointer.log).  Layout: by-value struct arguments sit back to back from offset 0 of the segment.
+  static_assert(sizeof(GemmParams) % 8 == 0 && alignof(GemmParams) == 8, "pb follows pa without padding");
+  typedef const __attribute__((address_space(4))) GemmParams karg_params_t;
+  const __attribute__((address_space(4))) char* kbase = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  karg_params_t& p = *(karg_params_t*)(kbase + (second ? sizeof(GemmParams) : 0));
   const int tl = second ? tile - tiles_a : tile;  // tile index inside its problem
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + T256 - 1) / T256;
 
