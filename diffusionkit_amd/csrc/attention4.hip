@@ -120,58 +120,6 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   const char* Kb = (const char*)(p.K + (size_t)b * S * p.ld + head * D);  // wave-uniform bases
   const char* Vb = (const char*)(p.V + (size_t)b * S * p.ld + head * D);
 
-  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][kk*16 + hi*8 .. +7]
-  bf16x8 qf[D / 16];
-  {
-    const int qrow = min(q0 + l31, S - 1);
-    const bf16_t* qp = Qb + (size_t)qrow * p.ld + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
-    if (QFUSE) {
-      // QKNorm + RoPE of this lane's query row on the fly (same fp32 arithmetic and bf16 rounding points as
-      // dk_qk_norm_rope_kernel): the lane and its partner (lane ^ 32) hold the two halves of every 16-element group
-      float v[D / 16][8];
-#pragma unroll
-      for (int kk = 0; kk < D / 16; ++kk)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[kk][e] = (float)qf[kk][e];
-      if (p.qn_a != nullptr) {
-        float ss = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < D / 16; ++kk)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ss += v[kk][e] * v[kk][e];
-        ss += __shfl_xor(ss, 32, 64);
-        const float r = rsqrtf(ss / (float)D + p.qn_eps);
-        const bf16_t* w = (qrow < p.qn_split ? p.qn_a : p.qn_b) + hi * 8;
-#pragma unroll
-        for (int kk = 0; kk < D / 16; ++kk) {
-          const bf16x8 wv = *(const bf16x8*)(w + kk * 16);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[kk][e] = round_bf16(v[kk][e] * r * (float)wv[e]);
-        }
-      }
-      if (p.q_rope != nullptr) {
-        const float* tab = p.q_rope + ((size_t)qrow * (D / 2) + hi * 4) * 2;
-#pragma unroll
-        for (int kk = 0; kk < D / 16; ++kk) {
-          const f32x4 t0 = *(const f32x4*)(tab + kk * 16), t1 = *(const f32x4*)(tab + kk * 16 + 4);
-          const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float c = cs[2 * i], sn = cs[2 * i + 1], xe = v[kk][2 * i], xo = v[kk][2 * i + 1];
-            v[kk][2 * i] = c * xe - sn * xo;
-            v[kk][2 * i + 1] = sn * xe + c * xo;
-          }
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < D / 16; ++kk)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)v[kk][e];
-    }
-  }
-
   u32x4 kreg[C::NCH], vreg[C::NCH];
   const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, -1, 0x00020000);
@@ -262,7 +210,70 @@ __global__ __launch_bounds__(512, 2) void dk_attn4_fwd_kernel(AttnParams p) {
   bf16x8 fr[8];  // fragment ring of the M phase
 
   // ---- prologue: K(0) by everybody; group B also what its (non-existent) V phase of tile -1 would store: K(1), V(0) ----
-  load_op(rK, kreg, 0, 64 <= S);
+  load_op(rK, kreg, 0, 64 <= S);  // (in flight while the query rows are fetched and prepared below: one memory round trip for the whole prologue)
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][kk*16 + hi*8 .. +7]
+  bf16x8 qf[D / 16];
+  {
+    const int qrow = min(q0 + l31, S - 1);
+    const bf16_t* qp = Qb + (size_t)qrow * p.ld + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+    if (QFUSE) {
+      // QKNorm + RoPE of this lane's query row on the fly (same fp32 arithmetic and bf16 rounding points as
+      // dk_qk_norm_rope_kernel): the lane and its partner (lane ^ 32) hold the two halves of every 16-element group.
+      // Round 4: the norm weights and the cos / sin table rows are FETCHED UP FRONT, next to the query row -- as written before
+      // (loads at their uses) the prologue was four dependent memory round trips (row, weights two at a time behind the reduction,
+      // table, then the first key tile): 12 us per FLUX launch over two rounds of workgroups (profiles/r04_attention_qfuse_in_model.log).
+      bf16x8 wv[D / 16];
+      f32x4 t0[D / 16], t1[D / 16];
+      if (p.qn_a != nullptr) {
+        const bf16_t* w = (qrow < p.qn_split ? p.qn_a : p.qn_b) + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) wv[kk] = *(const bf16x8*)(w + kk * 16);
+      }
+      if (p.q_rope != nullptr) {
+        const float* tab = p.q_rope + ((size_t)qrow * (D / 2) + hi * 4) * 2;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) t0[kk] = *(const f32x4*)(tab + kk * 16), t1[kk] = *(const f32x4*)(tab + kk * 16 + 4);
+      }
+      float v[D / 16][8];
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[kk][e] = (float)qf[kk][e];
+      if (p.qn_a != nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[kk][e] * v[kk][e];
+        ss += __shfl_xor(ss, 32, 64);
+        const float r = rsqrtf(ss / (float)D + p.qn_eps);
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[kk][e] = round_bf16(v[kk][e] * r * (float)wv[kk][e]);
+      }
+      if (p.q_rope != nullptr) {
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) {
+          const float cs[8] = {t0[kk][0], t0[kk][1], t0[kk][2], t0[kk][3], t1[kk][0], t1[kk][1], t1[kk][2], t1[kk][3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float c = cs[2 * i], sn = cs[2 * i + 1], xe = v[kk][2 * i], xo = v[kk][2 * i + 1];
+            v[kk][2 * i] = c * xe - sn * xo;
+            v[kk][2 * i + 1] = sn * xe + c * xo;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)v[kk][e];
+    }
+  }
+
 #pragma unroll
   for (int i = 0; i < C::NCH; ++i) {
     // K(0) -> slot 0 for both groups (ks_off carries the steady-state slot, which differs per group: take the slot bits out)
