@@ -456,6 +456,27 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
       // their scale bytes are the eight consecutive bytes of ONE word of the side array (dk_mx_scale_index: byte (r / 16) % 8) --
       // collected in two registers over the (fully unrolled) loop, stored once per lane quad and 32-column half
       unsigned sc_lo = 0u, sc_hi = 0u;
+      // FAST tiles: the residual rows (updated in place: the compiler may not move a row's load above the previous row's store) and the
+      // cos / sin entries of a key tile are fetched BEFORE the row loop -- one memory round trip per pass instead of one per row (round 4,
+      // gemm256v3.hip)
+      constexpr bool PRE_RES = FAST && (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES);
+      constexpr bool PRE_ROPE = FAST && KF;
+      uint4 res_pre[PRE_RES ? 8 : 1];
+      f32x4 rope_pre[PRE_ROPE ? 16 : 1];
+      if (PRE_RES) {
+#pragma unroll
+        for (int itr = 0; itr < 8; ++itr) res_pre[itr] = *(const uint4*)(p.res + (physR0 + itr * 16 + rrow) * (size_t)p_ldr + col);
+      }
+      if (PRE_ROPE) {
+        if (p.kn_rope != nullptr) {
+#pragma unroll
+          for (int itr = 0; itr < 8; ++itr) {
+            const int kpos_ = (mrow0 + itr * 16 + rrow) % p.kn_seg_len;
+            const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos_) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
+            rope_pre[2 * itr] = *(const f32x4*)tab, rope_pre[2 * itr + 1] = *(const f32x4*)(tab + 4);
+          }
+        }
+      }
 #pragma unroll
       for (int itr = 0; itr < 8; ++itr) {
         const int row = itr * 16 + rrow;  // row inside the wave's 128-row block
@@ -489,7 +510,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           if (p.kn_rope != nullptr) {
             const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
             f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
-            if (FAST || valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
+            if (PRE_ROPE) t0 = rope_pre[2 * itr], t1 = rope_pre[2 * itr + 1];
+            else if (valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
             const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -510,7 +532,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
         } else if (hres) {
           uint4 rr = make_uint4(0u, 0u, 0u, 0u);
-          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p_ldr + col);
+          if (PRE_RES) rr = res_pre[itr];
+          else if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p_ldr + col);
           float r8[8];
           unpack8(rr, r8);
           if (ep == DK_EPI_GATE_RES) {

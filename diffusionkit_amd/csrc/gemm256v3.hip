@@ -610,7 +610,29 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         if (hres) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
         if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
       }
-#pragma unroll 4
+      // FAST tiles: everything the rows read from memory is fetched BEFORE the row loop (round 4).  The residual is updated in place
+      // (C == res), so the compiler may not move a row's load above the previous row's store: as written before, every row of every
+      // pass was its own dependent memory round trip (16 per wave and tile; with the fused key norm two more loads per row for the cos /
+      // sin entries) -- the tail's latency chain.  One round trip per pass now; values and their order unchanged.
+      constexpr bool PRE_RES = FAST && BF && (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES);
+      constexpr bool PRE_ROPE = FAST && KF;
+      uint4 res_pre[PRE_RES ? MF : 1];
+      f32x4 rope_pre[PRE_ROPE ? 2 * MF : 1];
+      if (PRE_RES) {
+#pragma unroll
+        for (int itr = 0; itr < MF; ++itr) res_pre[itr] = *(const uint4*)(p.res + (physR0 + itr * 16 + rrow) * (size_t)p.ldr + col);
+      }
+      if (PRE_ROPE) {
+        if (p.kn_rope != nullptr) {
+#pragma unroll
+          for (int itr = 0; itr < MF; ++itr) {
+            const int kpos_ = (mrow0 + itr * 16 + rrow) % p.kn_seg_len;
+            const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos_) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
+            rope_pre[2 * itr] = *(const f32x4*)tab, rope_pre[2 * itr + 1] = *(const f32x4*)(tab + 4);
+          }
+        }
+      }
+#pragma unroll
       for (int itr = 0; itr < MF; ++itr) {
         const int row = itr * 16 + rrow;  // row inside the wave's block of HROWS rows
         size_t crow = physC0 + row, rrow_phys = physR0 + row;
@@ -673,7 +695,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
           if (p.kn_rope != nullptr) {
             const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
             f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
-            if (FAST || valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
+            if (PRE_ROPE) t0 = rope_pre[2 * itr], t1 = rope_pre[2 * itr + 1];
+            else if (valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
             const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -694,7 +717,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
           for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
         } else if (hres) {
           uint4 rr = make_uint4(0u, 0u, 0u, 0u);
-          if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
+          if (PRE_RES) rr = res_pre[itr];
+          else if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
           float r8[8];
           unpack8(rr, r8);
           if (ep == DK_EPI_GATE_RES) {
