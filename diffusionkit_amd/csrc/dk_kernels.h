@@ -50,6 +50,10 @@ struct GemmParams {
   const float* kn_rope;
   int kn_col0, kn_col1, kn_D, kn_pos_off, kn_seg_len;
   float kn_eps;
+  // round 4: the QUERY columns [qn_col0, qn_col1) the same way with their own weight qn_w (same head size, table, positions, eps) -- the
+  // attention kernel then loads finished queries.  Needs kn_w; null qn_w: queries untouched
+  const bf16_t* qn_w;
+  int qn_col0, qn_col1;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
 extern int g_dk_gemm_mode;
@@ -99,6 +103,8 @@ struct GemmF8Params {
   const float* kn_rope;
   int kn_col0, kn_col1, kn_D, kn_pos_off, kn_seg_len;
   float kn_eps;
+  const bf16_t* qn_w;  // ... and of the query columns [qn_col0, qn_col1) (see GemmParams)
+  int qn_col0, qn_col1;
 };
 bool dk_gemm256f8_eligible(const GemmF8Params& p);
 int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream_t stream);

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -20,6 +21,8 @@ extern "C" const char* dk_last_error(void) { return g_last_error.c_str(); }
 
 int g_dk_attn_mode = -1;
 int g_dk_fuse_k = 1;  // dk_tune_set("gemm_fuse_k", v): QKNorm + RoPE of the keys inside the q / k / v projection's tail (1, default) or as a separate pass (0)
+int g_dk_fuse_qg = -1;  // dk_tune_set("gemm_fuse_q", v): ... and of the QUERIES there too (1) instead of in the attention kernel's Q load (0); -1 (default): on
+                         // the fp8 path only -- measured in the model (profiles/r04_attention_qfuse_in_model.log): +1.0 % per step with fp8 weights, flat in bf16
 int g_dk_fuse_q = 1;  // dk_tune_set("attn_fuse_q", v): QKNorm + RoPE of the queries inside the attention kernel's Q load (1, default) or as a separate pass (0)
 // Rows of K >= g_dk_pitch_min_k elements (the [h, 5h] linear2 and [h, 4h] fc2 weights of FLUX and the activations they
 // multiply) are stored with 64 elements of padding: a 24-30 KB row stride makes the K-tile DMA of 256 rows camp on a few
@@ -41,6 +44,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "attn_balance") == 0) { g_dk_attn_balance = value; return 0; }
   if (strcmp(key, "gemm_fuse_k") == 0) { g_dk_fuse_k = value; return 0; }
+  if (strcmp(key, "gemm_fuse_q") == 0) { g_dk_fuse_qg = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
@@ -337,9 +341,12 @@ static int fuse_q() { return g_dk_fuse_q ? 1 : 0; }
 // the keys' QKNorm + RoPE rides in the q / k / v projection's tail (only together with the fused query side: the stand-alone pass
 // then has nothing left to do)
 static bool fuse_k(const bf16_t* kn) { return g_dk_fuse_k != 0 && fuse_q() && kn != nullptr; }
+// ... and the queries' with it (round 4): the attention kernel then loads finished queries
+static bool fuse_qg(const bf16_t* qn, bool f8) { return (g_dk_fuse_qg < 0 ? f8 : g_dk_fuse_qg != 0) && qn != nullptr; }
 template <typename P>
-static void set_key_norm(P& p, const bf16_t* kn, int h, int D, const float* rope, int pos_off, int seg_len) {
+static void set_key_norm(P& p, const bf16_t* kn, const bf16_t* qn, int h, int D, const float* rope, int pos_off, int seg_len) {
   p.kn_w = kn; p.kn_rope = rope; p.kn_col0 = h; p.kn_col1 = 2 * h; p.kn_D = D; p.kn_pos_off = pos_off; p.kn_seg_len = seg_len; p.kn_eps = 1e-6f;
+  if (fuse_qg(qn, std::is_same<P, GemmF8Params>::value)) { p.qn_w = qn; p.qn_col0 = 0; p.qn_col1 = h; }
 }
 
 // Split workspace (fp32 slabs + flags) handed to the GEMMs an engine call builds: every dk_mmdit_* entry point sets it to ITS
@@ -830,8 +837,8 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
       f8_out_bf16(qi, m->QKV + (size_t)S_t * 3 * h, 3 * h, S_i, S);
       f8_out_bf16(qt, m->QKV, 3 * h, S_t, S);
       if (fuse_k(wi.kn) && fuse_k(wt.kn)) {
-        set_key_norm(qi, wi.kn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
-        set_key_norm(qt, wt.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
+        set_key_norm(qi, wi.kn, wi.qn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
+        set_key_norm(qt, wt.kn, wt.qn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
       }
       DK_TRY(f8_pair(qi, &qt, st));
     }
@@ -841,7 +848,8 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
-    if (fuse_q()) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    // (queries finished by the projection's tail: plain Q load)
+    if (fuse_q() && !(fuse_k(wi.kn) && fuse_k(wt.kn) && fuse_qg(wi.qn, true) && fuse_qg(wt.qn, true))) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     // the o-projection's MX-fp8 operand comes out of the attention kernel (or out of a quantiser pass behind it: attention.hip)
     ap.O8 = m->ATT8; ap.O8_scales = m->SATT; ap.o8_ld = h; ap.o8_nblk = m->nblk;
     DK_TRY(dk_launch_attention(ap, st));
@@ -900,7 +908,7 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
       f8_out_bf16(l1, m->QKV, 3 * h, M, 0);
       l1.n_split = 3 * h; l1.C2 = m->HC8 + h; l1.ldc2 = ldcat8; l1.epi2 = DK_EPI_BIAS_GELU; l1.c2_mx8 = 1;
       l1.SC = m->SCAT; l1.sc_nblk = m->nblk; l1.c_row0 = 0; l1.sc_kb0 = h / 32;
-      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
+      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, w.qn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
       DK_TRY(f8_pair(l1, nullptr, st));
     }
     if (!fuse_k(w.kn))
@@ -909,7 +917,7 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
-    if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    if (fuse_q() && !(fuse_k(w.kn) && fuse_qg(w.qn, true))) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     ap.O8 = m->HC8; ap.O8_scales = m->SCAT; ap.o8_ld = ldcat8; ap.o8_nblk = m->nblk;  // [attn | gelu] operand of linear2: columns [0, h)
     DK_TRY(dk_launch_attention(ap, st));
     {  // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
@@ -965,8 +973,8 @@ static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int
     // QKNorm + RoPE: the keys in the projection's tail (or one pass over the buffer), the queries inside the attention kernel's Q load
     const bool kf = fuse_k(wi.kn) && fuse_k(wt.kn);
     if (kf) {
-      set_key_norm(qkv_img, wi.kn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
-      set_key_norm(qkv_txt, wt.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
+      set_key_norm(qkv_img, wi.kn, wi.qn, h, m->D(), c.use_rope ? m->rope : nullptr, S_t, S_i);
+      set_key_norm(qkv_txt, wt.kn, wt.qn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S_t);
     }
     DK_TRY(dk_launch_gemm_pair(qkv_img, qkv_txt, st));
     if (!kf)
@@ -975,7 +983,7 @@ static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->ATT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = h; ap.scale = scale;
-    if (fuse_q()) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    if (fuse_q() && !(kf && fuse_qg(wi.qn, false) && fuse_qg(wt.qn, false))) { ap.qn_a = wt.qn; ap.qn_b = wi.qn; ap.qn_split = S_t; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // post_sdpa, sequential form (mmdit.py:537-548): residual += gate_attn * o_proj(attn)
     const GemmParams o_img = linear_params(m->ATT + (size_t)S_t * h, h, S_i, S, wi.o_w, wi.o_b, X_img, h, S_i, S, Mi, h, h, DK_EPI_GATE_RES,
@@ -1024,7 +1032,7 @@ static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int
       GemmParams l1 = linear_params(m->XN, h, M, 0, w.qkv_w, w.qkv_b, m->QKV, 3 * h, M, 0, M, (3 + r) * h, h, DK_EPI_BIAS, nullptr, 0, 0,
                                     nullptr, 0, 0, 0);
       l1.n_split = 3 * h; l1.C2 = m->CAT + h; l1.ldc2 = ldcat; l1.epi2 = DK_EPI_BIAS_GELU;
-      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
+      if (fuse_k(w.kn)) set_key_norm(l1, w.kn, w.qn, h, m->D(), c.use_rope ? m->rope : nullptr, 0, S);
       DK_TRY(dk_launch_gemm(l1, st));
     }
     if (!fuse_k(w.kn))
@@ -1033,7 +1041,7 @@ static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int
     AttnParams ap;
     ap.Q = m->QKV; ap.K = m->QKV + h; ap.V = m->QKV + 2 * h; ap.O = m->CAT;
     ap.B = B; ap.H = c.num_heads; ap.S = S; ap.D = m->D(); ap.ld = 3 * h; ap.ldo = ldcat; ap.scale = scale;
-    if (fuse_q()) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
+    if (fuse_q() && !(fuse_k(w.kn) && fuse_qg(w.qn, false))) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
     DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, (1 + r) * h, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,

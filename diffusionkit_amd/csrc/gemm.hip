@@ -249,11 +249,15 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     // stand-alone pass over its key columns afterwards
     GemmParams plain = p;
     plain.kn_w = nullptr;
+    plain.qn_w = nullptr;
     const int rc = dk_launch_gemm(plain, stream);
     if (rc) return rc;
     DK_REQUIRE(p.c_seg_len == p.kn_seg_len || p.c_seg_len >= p.M, "fused key QKNorm: the output's row segments must be the sequences");
-    return dk_launch_qk_norm_rope(p.C, p.ldc, 0, p.kn_col0, p.M, (p.kn_col1 - p.kn_col0) / p.kn_D, p.kn_D, p.kn_w, p.kn_w, p.kn_eps, p.kn_rope,
-                                  p.kn_seg_len, p.c_seg_len == p.kn_seg_len ? p.c_seg_stride : p.kn_seg_len, p.kn_pos_off, 0, stream, 1);
+    // (with the query side asked for as well -- qn_w -- the pass covers both column ranges: they hold the same number of heads)
+    DK_REQUIRE(p.qn_w == nullptr || p.qn_col1 - p.qn_col0 == p.kn_col1 - p.kn_col0, "fused QKNorm: query and key ranges must hold the same heads");
+    return dk_launch_qk_norm_rope(p.C, p.ldc, p.qn_w ? p.qn_col0 : 0, p.kn_col0, p.M, (p.kn_col1 - p.kn_col0) / p.kn_D, p.kn_D, p.qn_w ? p.qn_w : p.kn_w, p.kn_w,
+                                  p.kn_eps, p.kn_rope, p.kn_seg_len, p.c_seg_len == p.kn_seg_len ? p.c_seg_stride : p.kn_seg_len, p.kn_pos_off, 0,
+                                  stream, p.qn_w ? 0 : 1);
   }
   if (p.n_split > 0) {
     // column-split GEMM on the kernel without split support: two GEMMs over the two column ranges

@@ -387,7 +387,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   // Key tile of a q / k / v projection with the fused QKNorm + RoPE (gemm256v3.hip has the bf16 twin): the sum of squares of every
   // row over its head's columns -- this wave's 64 columns from the accumulators, for 128-column heads plus the partner wave's
   // through LDS (behind the staging images)
-  const bool kfuse = p.kn_w != nullptr && !out2 && n0 >= p.kn_col0 && n0 < p.kn_col1;  // tile-uniform
+  const bool qtile = p.qn_w != nullptr && !out2 && n0 >= p.qn_col0 && n0 < p.qn_col1;  // query tile (round 4)
+  const bool kfuse = p.kn_w != nullptr && !out2 && ((n0 >= p.kn_col0 && n0 < p.kn_col1) || qtile);  // tile-uniform
+  const bf16_t* const nw = qtile ? p.qn_w : p.kn_w;
   constexpr unsigned XCH_OFF = 8u * 16384u;
   if (kfuse) {
 #pragma unroll
@@ -437,8 +439,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
       constexpr bool FAST = decltype(fast_c)::value;
       constexpr bool KF = decltype(kf_c)::value;  // key tile with the fused QKNorm + RoPE (bias-only epilogue, bf16 out)
       float kw8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int kcol = KF ? (col - p.kn_col0) % p.kn_D : 0;  // first of this lane's 8 columns inside its head
-      if (KF) unpack8(*(const uint4*)(p.kn_w + kcol), kw8);
+      const int kcol = KF ? col % p.kn_D : 0;  // first of this lane's 8 columns inside its head (the ranges start at multiples of 256)
+      if (KF) unpack8(*(const uint4*)(nw + kcol), kw8);
       constexpr int EK = decltype(ek_c)::value;  // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
       constexpr int MX = decltype(mx_c)::value;  // output: 1 MX-fp8, 0 bf16, -1: `out_mx8`
       const int ep = EK >= 0 ? EK : epi;
@@ -615,6 +617,11 @@ bool dk_gemm256f8_eligible(const GemmF8Params& p) {
     if (p.epi != DK_EPI_BIAS || p.c_mx8 || (p.kn_D != 128 && p.kn_D != 64) || p.kn_seg_len <= 0 || p.kn_col0 % 256 != 0 || p.kn_col1 % 256 != 0 ||
         p.kn_col0 >= p.kn_col1 || p.kn_col1 > (p.n_split > 0 ? p.n_split : p.N) || ((uintptr_t)p.kn_w & 15) != 0 || ((uintptr_t)p.kn_rope & 15) != 0)
       return false;
+    if (p.qn_w != nullptr && (p.qn_col0 % 256 != 0 || p.qn_col1 % 256 != 0 || p.qn_col0 >= p.qn_col1 || p.qn_col1 > (p.n_split > 0 ? p.n_split : p.N) ||
+                              (p.qn_col0 < p.kn_col1 && p.kn_col0 < p.qn_col1) || ((uintptr_t)p.qn_w & 15) != 0))
+      return false;
+  } else if (p.qn_w != nullptr) {
+    return false;  // the query side rides on the key side's machinery
   }
   // outputs: bf16 rows of 16-byte stores, or MX-fp8 rows of 8-byte stores with the scale side array
   auto al = [](const void* q, int a) { return ((uintptr_t)q & (uintptr_t)(a - 1)) == 0; };

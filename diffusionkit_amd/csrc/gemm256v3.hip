@@ -521,7 +521,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
   // Key tile of a q / k / v projection with the fused QKNorm + RoPE: the sum of squares of every row over its head's columns --
   // this wave's 64 columns from the accumulators (same bf16-rounded values that get staged), for 128-column heads plus the
   // partner wave's 64 through LDS (behind the staging images)
-  const bool kfuse = !CONV && p.kn_w != nullptr && piece < 0 && n0 >= p.kn_col0 && n0 < p.kn_col1;  // tile-uniform
+  const bool qtile = !CONV && p.qn_w != nullptr && n0 >= p.qn_col0 && n0 < p.qn_col1;  // query tile (round 4): same treatment, own weight
+  const bool kfuse = !CONV && p.kn_w != nullptr && piece < 0 && ((n0 >= p.kn_col0 && n0 < p.kn_col1) || qtile);  // tile-uniform
+  const bf16_t* const nw = qtile ? p.qn_w : p.kn_w;
   constexpr unsigned XCH_OFF = 8u * 16384u;
   if (kfuse) {
 #pragma unroll
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
       constexpr int EK = decltype(ek_c)::value;   // the epilogue as a compile-time constant (straight-line row loop), or -1: `epi`
       constexpr bool PLAIN = BF && EK == DK_EPI_BIAS && !KF;  // a bias-only epilogue on a bf16 image: the staged values ARE the output
       float kw8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int kcol = KF ? (col - p.kn_col0) % p.kn_D : 0;  // first of this lane's 8 columns inside its head
-      if (KF) unpack8(*(const uint4*)(p.kn_w + kcol), kw8);
+      const int kcol = KF ? col % p.kn_D : 0;  // first of this lane's 8 columns inside its head (the ranges start at multiples of 256)
+      if (KF) unpack8(*(const uint4*)(nw + kcol), kw8);
       const int ep = EK >= 0 ? EK : epi;
       const bool hres = EK >= 0 ? (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES) : has_res;
       if (FAST && ep == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
@@ -814,6 +816,11 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
     if (p.conv || p.epi != DK_EPI_BIAS || (p.kn_D != 128 && p.kn_D != 64) || p.kn_seg_len <= 0 || p.kn_col0 % 256 != 0 || p.kn_col1 % 256 != 0 || p.kn_col0 >= p.kn_col1 ||
         p.kn_col1 > (p.n_split > 0 ? p.n_split : p.N) || ((uintptr_t)p.kn_w & 15) != 0 || ((uintptr_t)p.kn_rope & 15) != 0)
       return false;
+    if (p.qn_w != nullptr && (p.qn_col0 % 256 != 0 || p.qn_col1 % 256 != 0 || p.qn_col0 >= p.qn_col1 || p.qn_col1 > (p.n_split > 0 ? p.n_split : p.N) ||
+                              (p.qn_col0 < p.kn_col1 && p.kn_col0 < p.qn_col1) || ((uintptr_t)p.qn_w & 15) != 0))
+      return false;
+  } else if (p.qn_w != nullptr) {
+    return false;  // the query side rides on the key side's machinery
   }
   // 16-byte accesses in the tail
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };

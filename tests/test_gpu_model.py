@@ -324,8 +324,8 @@ def test_flux_width_block_pair_full_sequence(dev):
 
 @pytest.mark.parametrize("B,mf,side", [(1, -1, 128), (2, 8, 128), (2, 7, 128), (1, 8, 104), (2, 7, 104)])
 def test_fused_key_norm_matches_separate_pass(dev, B, mf, side):
-    """QKNorm + RoPE of the keys inside the q / k / v projection's tail (dk_tune_set("gemm_fuse_k", 1), default) against the
-    stand-alone pass over the projection's output (0): FLUX geometry, depth 1+1 -- double block (two streams, own weights and
+    """QKNorm + RoPE of the keys -- and, round 4, of the queries (dk_tune_set("gemm_fuse_q", 1); default on the fp8 path) -- inside the q / k / v
+    projection's tail (dk_tune_set("gemm_fuse_k", 1), default) against the stand-alone pass over the projection's output (0): FLUX geometry, depth 1+1 -- double block (two streams, own weights and
     positions) and single block (column-split linear1); two images: rows of both sequences inside one launch, with 224-row tiles
     straddling the sequence boundary; latent side 104: 2704 image tokens, the last tile of every stream ragged.  Same values up to
     the summation order of a head's squares."""
@@ -342,17 +342,24 @@ def test_fused_key_norm_matches_separate_pass(dev, B, mf, side):
     outs = {}
     try:
         ops.tune("gemm_mf", mf)
-        for fuse in (1, 0):
-            ops.tune("gemm_fuse_k", fuse)
+        # (keys, queries) in the projection's tail: (1, 1) round 4's form, the default on the fp8 path -- the attention kernel loads finished
+        # queries --, (1, 0) queries in the attention kernel's Q load (the bf16 default), (0, x) the stand-alone pass for the keys
+        for fuse in ((1, 1), (1, 0), (0, 1)):
+            ops.tune("gemm_fuse_k", fuse[0])
+            ops.tune("gemm_fuse_q", fuse[1])
             outs[fuse] = eng.forward_tokens(tok, text.to(dev, BF), 1).float().cpu()
     finally:
         ops.tune("gemm_fuse_k", 1)
+        ops.tune("gemm_fuse_q", -1)
         ops.tune("gemm_mf", -1)
-    d = (outs[1] - outs[0]).abs()
-    assert torch.isfinite(outs[1]).all()
-    # (a key that lands one bf16 ulp away moves its whole score column: 3e-3 after the two blocks)
-    assert rel_l2(outs[0], outs[1]) < 8e-3, float(rel_l2(outs[0], outs[1]))
-    assert float(d.max()) <= 0.05 * float(outs[0].abs().max())
+    ref = outs[(0, 1)]
+    assert torch.isfinite(outs[(1, 1)]).all()
+    for key in ((1, 1), (1, 0)):
+        d = (outs[key] - ref).abs()
+        # (a key or query that lands one bf16 ulp away moves its whole score column / row: 3e-3 after the two blocks)
+        assert rel_l2(ref, outs[key]) < 8e-3, (key, float(rel_l2(ref, outs[key])))
+        assert float(d.max()) <= 0.05 * float(ref.abs().max()), key
+    assert not torch.equal(outs[(1, 1)], outs[(1, 0)])  # (the switch does select another path: the sums of squares differ in their order)
 
 
 @pytest.mark.parametrize("B,side", [(1, 128), (2, 104)])
