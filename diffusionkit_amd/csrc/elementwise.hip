@@ -17,73 +17,82 @@ struct LnJob {
   const bf16_t *shift, *scale;
   int ldx, ldo, M, mod_stride, seg_len, x_seg_len, x_seg_stride;
 };
+// Every load of the row -- its NCH chunks, then the shift and scale chunks -- is issued unconditionally and back to back before
+// the first use: one memory round trip per wave.  Guarding each chunk with `if (c < nchunks)` compiled to branch / load /
+// s_waitcnt vmcnt(0) per chunk, twelve dependent round trips at h = 3072.  The loads and the store are buffer instructions
+// whose resource spans exactly one row (h * 2 bytes from a scalar row base): lanes past the row end read zeros and their stores
+// are dropped, one 32-bit offset register serves all three arrays, and the row stays in its packed bf16 form (unpacked again
+// in each pass) so the kernel holds 12 * NCH data registers.
+static_assert(sizeof(LnJob) % 8 == 0 && alignof(LnJob) == 8, "job b follows job a without padding in the kernarg segment");
 template <int NCH>
 __global__ __launch_bounds__(256) void dk_ln_modulate_kernel(LnJob ja, LnJob jb, int blocks_a, int h, float eps) {
   const bool first = (int)blockIdx.x < blocks_a;
-  const LnJob& j = first ? ja : jb;
-  const bf16_t* __restrict__ x = j.x;
-  bf16_t* __restrict__ out = j.out;
-  const bf16_t* __restrict__ shift = j.shift;
-  const bf16_t* __restrict__ scale = j.scale;
-  const int ldx = j.ldx, ldo = j.ldo, M = j.M, mod_stride = j.mod_stride, seg_len = j.seg_len, x_seg_len = j.x_seg_len,
-            x_seg_stride = j.x_seg_stride;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // one scalar base pointer into the kernarg segment (`first ? ja : jb` copies both jobs to scratch, see gemm256v3.hip)
+  typedef const __attribute__((address_space(4))) LnJob karg_job_t;
+  const __attribute__((address_space(4))) char* kbase = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  karg_job_t& j = *(karg_job_t*)(kbase + (first ? 0 : sizeof(LnJob)));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: row bases live in SGPRs)
   const int m = ((int)blockIdx.x - (first ? 0 : blocks_a)) * 4 + wave;
-  if (m >= M) return;
-  const size_t xrow = (size_t)((m / x_seg_len) * x_seg_stride + (m % x_seg_len)) * ldx;
-  const int b = m / seg_len;
+  if (m >= j.M) return;
+  const size_t xrow = (size_t)((m / j.x_seg_len) * j.x_seg_stride + (m % j.x_seg_len)) * j.ldx;
+  const size_t mod = (size_t)(m / j.seg_len) * j.mod_stride;
   const int nchunks = h >> 3;
-  float v[NCH][8];
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(j.x + xrow), 0, h * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)(j.shift + mod), 0, h * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(j.scale + mod), 0, h * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(j.out + (size_t)m * j.ldo), 0, h * 2, 0x00020000);
+  u32x4 raw[NCH], rs[NCH], rc[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (lane + 64 * i) * 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    rs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsh, (lane + 64 * i) * 16, 0, 0);
+    rc[i] = __builtin_amdgcn_raw_buffer_load_b128(rsc, (lane + 64 * i) * 16, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (without it the scheduler sinks the shift / scale loads below the two reductions)
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
-      const u32x4 raw = *(const u32x4*)(x + xrow + c * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unpack2bf(raw[e], v[i][2 * e], v[i][2 * e + 1]);
-        sum += v[i][2 * e] + v[i][2 * e + 1];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    for (int e = 0; e < 4; ++e) {
+      float v0, v1;
+      unpack2bf(raw[i][e], v0, v1);
+      sum += v0 + v1;  // (zeros past the row end)
     }
   }
   const float mean = wave_sum(sum) / (float)h;
+  __builtin_amdgcn_sched_barrier(0);  // (this one and the next two keep each pass's unpacked values out of the others' live ranges)
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
+    const bool live = lane + 64 * i < nchunks;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[i][e] - mean;
-        sq += d * d;
-      }
+    for (int e = 0; e < 4; ++e) {
+      float v0, v1;
+      asm volatile("" : "+v"(raw[i][e]));  // (opaque: else the unpacked row of pass 1 is kept live, 8 registers per chunk instead of 4)
+      unpack2bf(raw[i][e], v0, v1);
+      const float d0 = live ? v0 - mean : 0.f, d1 = live ? v1 - mean : 0.f;  // (masked before the product: sq += d * d stays one fma)
+      sq += d0 * d0;
+      sq += d1 * d1;
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)h + eps);
-  const bf16_t* sh = shift + (size_t)b * mod_stride;
-  const bf16_t* sc = scale + (size_t)b * mod_stride;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
-      const u32x4 rs = *(const u32x4*)(sh + c * 8);
-      const u32x4 rc = *(const u32x4*)(sc + c * 8);
-      u32x4 o;
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s0, s1, c0, c1;
-        unpack2bf(rs[e], s0, s1);
-        unpack2bf(rc[e], c0, c1);
-        const float y0 = (v[i][2 * e] - mean) * rstd * round_bf16(1.0f + c0) + s0;
-        const float y1 = (v[i][2 * e + 1] - mean) * rstd * round_bf16(1.0f + c1) + s1;
-        o[e] = pack2bf(y0, y1);
-      }
-      *(u32x4*)(out + (size_t)m * ldo + c * 8) = o;
+    for (int e = 0; e < 4; ++e) {
+      float v0, v1, s0, s1, c0, c1;
+      asm volatile("" : "+v"(raw[i][e]));  // (and v - mean of pass 2 likewise)
+      unpack2bf(raw[i][e], v0, v1);
+      unpack2bf(rs[i][e], s0, s1);
+      unpack2bf(rc[i][e], c0, c1);
+      const float y0 = (v0 - mean) * rstd * round_bf16(1.0f + c0) + s0;
+      const float y1 = (v1 - mean) * rstd * round_bf16(1.0f + c1) + s1;
+      o[e] = pack2bf(y0, y1);
     }
+    __builtin_amdgcn_raw_buffer_store_b128(o, ro, (lane + 64 * i) * 16, 0, 0);
   }
 }
 

@@ -14,80 +14,94 @@ struct Mx8Job {
   Mx8Out o;
 };
 
+// Memory schedule as in dk_ln_modulate_kernel (elementwise.hip): every load of the row -- and of its shift / scale chunks -- goes
+// out back to back ahead of the first use, through buffer resources that span exactly one row (lanes past the row end read
+// zeros, their element stores are dropped), and the row stays packed between the passes.
+static_assert(sizeof(Mx8Job) % 8 == 0 && alignof(Mx8Job) == 8, "job b follows job a without padding in the kernarg segment");
 template <int NCH, bool LN>
 __global__ __launch_bounds__(256) void dk_rows_to_mx8_kernel(Mx8Job ja, Mx8Job jb, int blocks_a, int h, float eps) {
   const bool first = (int)blockIdx.x < blocks_a;
-  const Mx8Job& j = first ? ja : jb;
-  const bf16_t* __restrict__ x = j.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  typedef const __attribute__((address_space(4))) Mx8Job karg_job_t;  // one scalar base pointer, see gemm256v3.hip
+  const __attribute__((address_space(4))) char* kbase = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  karg_job_t& j = *(karg_job_t*)(kbase + (first ? 0 : sizeof(Mx8Job)));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = ((int)blockIdx.x - (first ? 0 : blocks_a)) * 4 + wave;
   if (m >= j.M) return;
   const size_t xrow = (size_t)((m / j.x_seg_len) * j.x_seg_stride + (m % j.x_seg_len)) * j.ldx;
   const int nchunks = h >> 3;  // a multiple of 4: every quad of lanes holds whole 32-element blocks
-  float v[NCH][8];
-  float sum = 0.f;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(j.x + xrow), 0, h * 2, 0x00020000);
+  u32x4 raw[NCH], rs[NCH], rc[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunks) {
-      const u32x4 raw = *(const u32x4*)(x + xrow + c * 8);
+  for (int i = 0; i < NCH; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (lane + 64 * i) * 16, 0, 0);
+  if (LN) {
+    const size_t mod = (size_t)(m / j.seg_len) * j.mod_stride;
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)(j.shift + mod), 0, h * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(j.scale + mod), 0, h * 2, 0x00020000);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unpack2bf(raw[e], v[i][2 * e], v[i][2 * e + 1]);
-        sum += v[i][2 * e] + v[i][2 * e + 1];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    for (int i = 0; i < NCH; ++i) {
+      rs[i] = __builtin_amdgcn_raw_buffer_load_b128(rsh, (lane + 64 * i) * 16, 0, 0);
+      rc[i] = __builtin_amdgcn_raw_buffer_load_b128(rsc, (lane + 64 * i) * 16, 0, 0);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the shift / scale loads above the reductions)
+  float mean = 0.f, rstd = 0.f;
   if (LN) {
-    const float mean = wave_sum(sum) / (float)h;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0, v1;
+        unpack2bf(raw[i][e], v0, v1);
+        sum += v0 + v1;  // (zeros past the row end)
+      }
+    }
+    mean = wave_sum(sum) / (float)h;
+    __builtin_amdgcn_sched_barrier(0);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunks) {
+      const bool live = lane + 64 * i < nchunks;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = v[i][e] - mean;
-          sq += d * d;
-        }
+      for (int e = 0; e < 4; ++e) {
+        float v0, v1;
+        asm volatile("" : "+v"(raw[i][e]));  // (opaque: the unpacked row of the first pass must not stay live)
+        unpack2bf(raw[i][e], v0, v1);
+        const float d0 = live ? v0 - mean : 0.f, d1 = live ? v1 - mean : 0.f;
+        sq += d0 * d0;
+        sq += d1 * d1;
       }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)h + eps);
-    const int b = m / j.seg_len;
-    const bf16_t* sh = j.shift + (size_t)b * j.mod_stride;
-    const bf16_t* sc = j.scale + (size_t)b * j.mod_stride;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunks) {
-        const u32x4 rs = *(const u32x4*)(sh + c * 8);
-        const u32x4 rc = *(const u32x4*)(sc + c * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float s0, s1, c0, c1;
-          unpack2bf(rs[e], s0, s1);
-          unpack2bf(rc[e], c0, c1);
-          // the bf16 value dk_ln_modulate_kernel would have stored (same expression, same rounding), then quantised
-          v[i][2 * e] = round_bf16((v[i][2 * e] - mean) * rstd * round_bf16(1.0f + c0) + s0);
-          v[i][2 * e + 1] = round_bf16((v[i][2 * e + 1] - mean) * rstd * round_bf16(1.0f + c1) + s1);
-        }
-      }
-    }
+    rstd = rsqrtf(wave_sum(sq) / (float)h + eps);
   }
-  const Mx8Out& o = j.o;
-  const unsigned orow = (unsigned)(o.row0 + (m / o.seg_len) * o.seg_stride + (m % o.seg_len));
+  const unsigned orow = (unsigned)(j.o.row0 + (m / j.o.seg_len) * j.o.seg_stride + (m % j.o.seg_len));
+  const unsigned col0 = (unsigned)j.o.col0, n_blk128 = (unsigned)j.o.n_blk128;
+  unsigned char* __restrict__ scales = j.o.scales;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(j.o.out + (size_t)orow * j.o.ldo + col0), 0, h, 0x00020000);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
     const int c = lane + 64 * i;  // (the exchanges inside dk_mx8_quantize8 run for every lane of the wave: no divergence above it)
-    unsigned e8;
-    const uint2 q8 = dk_mx8_quantize8(v[i], e8);
-    if (c < nchunks) {
-      *(uint2*)(o.out + (size_t)orow * o.ldo + o.col0 + c * 8) = q8;
-      if ((lane & 3) == 0) o.scales[dk_mx_scale_index(orow, (unsigned)((o.col0 >> 5) + (c >> 2)), (unsigned)o.n_blk128)] = (unsigned char)e8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (LN) asm volatile("" : "+v"(raw[i][e]));
+      unpack2bf(raw[i][e], v[2 * e], v[2 * e + 1]);
+      if (LN) {
+        float s0, s1, c0, c1;
+        unpack2bf(rs[i][e], s0, s1);
+        unpack2bf(rc[i][e], c0, c1);
+        // the bf16 value dk_ln_modulate_kernel would have stored (same expression, same rounding), then quantised
+        v[2 * e] = round_bf16((v[2 * e] - mean) * rstd * round_bf16(1.0f + c0) + s0);
+        v[2 * e + 1] = round_bf16((v[2 * e + 1] - mean) * rstd * round_bf16(1.0f + c1) + s1);
+      }
     }
+    unsigned e8;
+    const uint2 q8 = dk_mx8_quantize8(v, e8);
+    u32x2 q;
+    q[0] = q8.x; q[1] = q8.y;
+    __builtin_amdgcn_raw_buffer_store_b64(q, ro, c * 8, 0, 0);
+    if (c < nchunks && (lane & 3) == 0) scales[dk_mx_scale_index(orow, (col0 >> 5) + (unsigned)(c >> 2), n_blk128)] = (unsigned char)e8;
   }
 }
 
