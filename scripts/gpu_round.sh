@@ -77,7 +77,7 @@ for ST in $STAGES; do
       echo "run $NAME exit $?"; tail -n 25 $OUT/${NAME%.*}.log ;;
     custom)
       V="CUSTOM_$NAME"; echo "+ ${!V}" > $OUT/custom_$NAME.log
-      ( eval "timeout 1200 ${!V}" ) >> $OUT/custom_$NAME.log 2>&1; echo "custom $NAME exit $?"; tail -n 40 $OUT/custom_$NAME.log ;;
+      timeout 1200 bash -c "${!V}" >> $OUT/custom_$NAME.log 2>&1; echo "custom $NAME exit $?"; tail -n 40 $OUT/custom_$NAME.log ;;
     *) echo "unknown stage $ST" ;;
   esac
   echo "[stage $ST: $(( $(date +%s) - T0 )) s]"
