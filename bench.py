@@ -75,7 +75,8 @@ def cpu_sample_config(cfg):
     from math import gcd
     dm, du = cfg.depth_multimodal, cfg.depth_unified
     f = gcd(dm, du) if du else (dm // 2 if dm % 2 == 0 else dm)
-    return replace(cfg, depth_multimodal=dm // f, depth_unified=du // f), f
+    # (SD3 derives its width from the depth -- 64 x depth_multimodal: the sample keeps the workload's width)
+    return replace(cfg, depth_multimodal=dm // f, depth_unified=du // f, hidden_size_override=cfg.hidden_size), f
 
 
 def cpu_baseline(workload, threads=None):

@@ -166,3 +166,20 @@ def test_tune_keys_and_workspace_sizes():
     assert lib.dk_gemm_workspace_bytes() == 256 * 256 * 256 * 4 + 4096
     assert lib.dk_attention_workspace_bytes() % 1024 == 0 and lib.dk_attention_workspace_bytes() > 4096
     assert lib.dk_attention_set_workspace(None, 0) == 0
+
+
+def test_bench_cpu_sample_keeps_the_workload_width():
+    """bench.py's bounded CPU sample (`cpu_sample_config`) is the workload's model with 1/f of its blocks: same width and head size
+    (SD3 derives its width from the depth, 64 x depth_multimodal -- the sample must not shrink it), block ratio kept; and
+    `cpu_baseline` runs end to end on a small SD3-style workload (two conditioning rows)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from diffusionkit_amd.config import FLUX_DEV, SD3_8b
+    for cfg, blocks, f in ((FLUX_SCHNELL, (1, 2), 19), (FLUX_DEV, (1, 2), 19), (SD3_2b, (2, 0), 12), (SD3_8b, (2, 0), 19)):
+        scfg, ff = bench.cpu_sample_config(cfg)
+        assert (scfg.depth_multimodal, scfg.depth_unified, ff) == (*blocks, f)
+        assert scfg.hidden_size == cfg.hidden_size and scfg.head_dim == cfg.head_dim and scfg.num_heads == cfg.num_heads
+    cfg = tiny_sd3(depth=4)
+    out = bench.cpu_baseline({"cfg": cfg, "latent": (8, 8), "num_steps": 2, "S_t": 24, "rows": 2}, threads=2)
+    assert out["value"] > 0 and out["kind"] == "port" and out["cores"] == 2
