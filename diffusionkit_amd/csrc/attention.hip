@@ -15,7 +15,8 @@
 // r02_attn_bench.log): the lean kernel at 8 and 7 waves, the pipelined kernel at 4 waves and for D = 64 (842 TF lean against 773 / 823).
 // Round 4: a D = 64 form with two query blocks per wave (half the LDS bytes per MFMA) measured +1.3 % isolated and +0.4 % / -0.9 % inside
 // SD3-medium / SD3.5-large -- the lean kernel at D = 64 is bound by VALU issue, not by the LDS (profiles/r04_sd3_pmc.md,
-// profiles/lab_kernels/attention5_two_query_blocks.hip); not built.
+// profiles/lab_kernels/attention5_two_query_blocks.hip); not built.  Nor is its pipelined form (next tile's score MFMAs under this tile's
+// exponentials, a sched_group_barrier pipeline: parity-green, 6 % slower at 2 waves per SIMD; profiles/lab_kernels/attention2_pipelined.patch).
 #include "dk_kernels.h"
 
 extern int g_dk_attn_mode;  // dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 7 = dk_attn3, 9 = dk_attn4 (8 waves, D = 128 only)

@@ -310,17 +310,31 @@ static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   return 0;
 }
 
+#ifdef DK_ATTN2_DEFAULT_SCHED_TU
+// attention2p.hip: this file compiled a second time, under LLVM's default machine scheduler, for the D = 128 instantiations -- the
+// iterative-ilp strategy the D = 64 kernels are built under (Makefile) drives them into spills (5 registers with the fused query norm).
+// (Round 4 lab, profiles/lab_kernels/attention2_pipelined.patch: a D = 64 form with the next tile's score MFMAs and this tile's P.V
+// MFMAs interleaved with the exponentials by a sched_group_barrier pipeline -- parity-green, 200 registers = 2 waves per SIMD,
+// 6 % SLOWER than the lean form on the SD3 shapes, profiles/r04_attention_d64_pipelined.log; not built.)
+int dk_launch_attention2_d128(const AttnParams& p, hipStream_t stream) {  // (arguments checked by dk_launch_attention2)
+  if (p.bias != nullptr) return launch_attn2<128, 4, true>(p, stream);
+  if (p.qn_a != nullptr || p.q_rope != nullptr) return launch_attn2<128, 4, false, true>(p, stream);
+  return launch_attn2<128, 4>(p, stream);
+}
+#else
+int dk_launch_attention2_d128(const AttnParams& p, hipStream_t stream);  // attention2p.hip
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream) {
   DK_REQUIRE((size_t)p.S * p.ld * 2 < (1ull << 32), "attention2: one batch row of QKV must span < 4 GiB");
   if (p.bias != nullptr) {  // text encoders: D = 64, short sequences
     DK_REQUIRE(p.ldb % 64 == 0 && p.ldb >= p.S && ((uintptr_t)p.bias & 7) == 0 && p.bias_head_stride % 4 == 0,
                "attention bias: row stride must be a multiple of 64 >= S, 8-byte aligned");
-    return p.D == 128 ? launch_attn2<128, 4, true>(p, stream) : launch_attn2<64, 4, true>(p, stream);
+    return p.D == 128 ? dk_launch_attention2_d128(p, stream) : launch_attn2<64, 4, true>(p, stream);
   }
   DK_REQUIRE(waves == 4, "attention2: 4 waves per workgroup (the 8- and 7-wave forms were pruned in round 3)");
   if (p.qn_a != nullptr || p.q_rope != nullptr) {  // query-side QKNorm / RoPE fused into the Q load (MMDiT call sites)
     DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
-    return p.D == 128 ? launch_attn2<128, 4, false, true>(p, stream) : launch_attn2<64, 4, false, true>(p, stream);
+    return p.D == 128 ? dk_launch_attention2_d128(p, stream) : launch_attn2<64, 4, false, true>(p, stream);
   }
-  return p.D == 128 ? launch_attn2<128, 4>(p, stream) : launch_attn2<64, 4>(p, stream);
+  return p.D == 128 ? dk_launch_attention2_d128(p, stream) : launch_attn2<64, 4>(p, stream);
 }
+#endif

@@ -393,11 +393,11 @@ def test_attention(dev, B, H, S, D):
 
 @pytest.mark.parametrize("mode", [4, 7, 9])
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 2, 129, 128), (1, 2, 192, 128), (1, 2, 250, 128), (1, 3, 1088, 128),
-                                     (2, 2, 589 + 64, 64)])
+                                     (2, 2, 589 + 64, 64), (1, 2, 64, 64), (1, 2, 128, 64), (1, 2, 129, 64), (1, 2, 192, 64), (1, 3, 1088 + 31, 64)])
 def test_attention_kernel_variants(dev, mode, B, H, S, D):
     """The attention kernels behind dk_tune_set("attn", mode) (4: the VALU-lean kernel with the deferred rescale, 7: the
     software-pipelined kernel, 9: the phase-alternating kernel, both D = 128; for D = 64 they fall back to the lean kernel) against
-    the oracle; ragged tail tile, one to 17 key tiles (the phase-alternating kernel's two wave groups stage different tiles)."""
+    the oracle; ragged tail tile, one to 18 key tiles (the phase-alternating kernel's two wave groups stage different tiles)."""
     from diffusionkit_amd import ops
     h = H * D
     qkv = randn(B, S, 3 * h, seed=32)
@@ -492,6 +492,26 @@ def test_attention_spiked_key_forces_rescale(dev):
         finally:
             ops.tune("attn", -1)
         assert rel_l2(ref, y.float()) < 6e-3, mode
+
+
+@pytest.mark.parametrize("mode", [4])
+def test_attention_spiked_key_forces_rescale_d64(dev, mode):
+    """The same at D = 64 (two heads, the spike in head 0 only); fp64 reference."""
+    from diffusionkit_amd import ops
+    B, H, S, D = 1, 2, 400, 64
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=33, scale=0.5)
+    qkv[0, 330, h:h + D] = bf16r(qkv[0, 9, :D] * 8.0)  # head 0: key 330 aligned with query 9
+    q, k, v = (qkv[..., i * h:(i + 1) * h].double().reshape(S, H, D).transpose(0, 1) for i in range(3))
+    p = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(D), dim=-1)
+    ref = (p @ v).transpose(0, 1).reshape(1, S, h)
+    assert float(p[0, 9, 330]) > 0.9
+    try:
+        ops.tune("attn", mode)
+        y = ops.attention(g(qkv, dev), H, D)
+    finally:
+        ops.tune("attn", -1)
+    assert rel_l2(ref, y.float()) < 6e-3
 
 
 # ---- normalisation / elementwise ------------------------------------------------------------------
