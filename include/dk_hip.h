@@ -384,10 +384,14 @@ int dk_latent_sample_f32(const void* moments_bf16, int32_t ldm, const float* noi
 int dk_profile_enable(int32_t on);
 int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops, int64_t* launches);
 
-/* Tuning knobs for A/B measurements (no reference counterpart).  key "gemm": -1 automatic kernel choice (default),
- * 128 = 128x128 tiles only, 9 = 256x256 tiles on every shape they accept; "gemm_mf": 8 / 7 = 256- / 224-row tiles;
- * "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "attn": kernel variant of dk_attention_bf16
- * (4 / 5 / 6 lean kernel with 4 / 8 / 7 waves, 7 / 8 pipelined kernel with 8 / 4 waves); -1 = automatic for every key.
+/* Tuning knobs for A/B measurements (no reference counterpart); -1 = automatic (the shipped default) for every key.
+ * "gemm": 128 = 128x128 tiles only, 9 = 256x256 tiles on every shape they accept; "gemm_mf": 8 / 7 = 256- / 224-row tiles;
+ * "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
+ * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
+ * 7 pipelined kernel, 9 phase-alternating kernel; 7 and 9 exist for head_dim 128 and fall back to 4 otherwise);
+ * "attn_balance": 1 = balanced launch of kernel 7 (needs dk_attention_set_workspace); "attn_fuse_q": 0 = stand-alone query
+ * QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form; "vae_attn": 0 = VAE mid-block attention through a materialised score matrix instead of the flash kernel;
+ * "pitch_min_k": rows of at least this many elements are stored padded (dk_weight_pitch).
  * Returns 0, or -1 for an unknown key. */
 int dk_tune_set(const char* key, int32_t value);
 
