@@ -1,0 +1,60 @@
+"""Codegen guards (CPU; reads the gfx950 code objects the build left under diffusionkit_amd/csrc/build/): the hot kernels must stay free of
+register spills and scratch.  Round 4 found two defects of this kind by reading the ISA -- a parameter-block select that had become a
+scratch copy in the fp8 GEMM (105 scratch_load sites, -7..12 % per launch) and D = 128 attention kernels spilling under a scheduler
+strategy meant for their D = 64 siblings -- neither of which any numerical test can see."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "diffusionkit_amd", "csrc", "build")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernels on the denoise / decode path (mangled-name fragments)
+HOT = ["dk_gemm256v3_kernel", "dk_gemm256f8_kernel", "dk_attn4_fwd_kernel", "dk_attn2_fwd_kernel", "dk_attn512_fwd_kernel", "dk_conv_halo_kernel",
+       "dk_ln_modulate_kernel", "dk_rows_to_mx8_kernel", "dk_euler_step_kernel", "dk_qk_norm_rope_kernel"]
+
+
+def kernel_metadata(obj):
+    """{kernel name: {vgpr, sgpr, spill, scratch, lds}} from the code object's notes."""
+    with tempfile.TemporaryDirectory() as t:
+        r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={t}/fb.bin", obj, f"{t}/copy.o"], capture_output=True)
+        if r.returncode != 0:
+            return {}  # host-only object (no device code)
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={t}/fb.bin",
+                               f"--output={t}/k.co", "--unbundle"])
+        notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", f"{t}/k.co"], text=True)
+    out, cur = {}, {}
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s+(\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k in ("name", "vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
+            cur[k] = v
+        if k == "wavefront_size" and "name" in cur:  # last field of a kernel's record
+            out[cur["name"]] = {kk: int(vv) for kk, vv in cur.items() if kk != "name"}
+            cur = {}
+    return out
+
+
+@pytest.mark.skipif(not (os.path.isdir(BUILD) and glob.glob(os.path.join(BUILD, "*.o")) and shutil.which(f"{LLVM}/llvm-readelf")),
+                    reason="needs the built objects (make -C diffusionkit_amd/csrc) and the ROCm LLVM tools")
+def test_hot_kernels_have_no_spills_and_no_scratch():
+    seen, bad = set(), []
+    for obj in sorted(glob.glob(os.path.join(BUILD, "*.o"))):
+        for name, md in kernel_metadata(obj).items():
+            hot = next((h for h in HOT if h in name), None)
+            if hot is None:
+                continue
+            seen.add(hot)
+            if md.get("vgpr_spill_count", 0) or md.get("sgpr_spill_count", 0) or md.get("private_segment_fixed_size", 0):
+                bad.append((os.path.basename(obj), name, md))
+            assert md["vgpr_count"] <= 256, (name, md)  # two waves per SIMD at least
+    assert not bad, "spills / scratch in hot kernels:\n" + "\n".join(f"{o}: {n}: {m}" for o, n, m in bad)
+    assert seen == set(HOT), f"hot kernels not found in the build: {sorted(set(HOT) - seen)}"
