@@ -231,8 +231,14 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
 }
 
 // tuning knob (dk_tune_set("gemm", v)): -1 = automatic choice, 128 = always the 128^2-tile kernel of this file, 9 = the 256^2 kernel
-// (gemm256v3.hip) on every shape it accepts
+// (gemm256v3.hip) on every shape it accepts, 10 = the one-wave-per-SIMD 256^2 kernel (gemm256v4.hip) on every shape IT accepts (others: 9)
 int g_dk_gemm_mode = -1;
+
+// which of the two 256^2 kernels takes a launch both accept
+static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
+  if (g_dk_gemm_mode != 10) return false;
+  return dk_gemm256v4_eligible(a) && (b == nullptr || dk_gemm256v4_eligible(*b));
+}
 
 int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
@@ -241,8 +247,9 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
   // the 256^2 kernel (16x16x32 MFMA, LDS-DMA ring, any M and any row-segment map) takes every large-M shape it accepts; small M
   // (modulation tables, embedders, a lone text stream) and N % 256 != 0 stay on the 128^2 tiles
-  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9);
-  if (g_dk_gemm_mode == 9 && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
+  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9 || g_dk_gemm_mode == 10);
+  if ((g_dk_gemm_mode == 9 || g_dk_gemm_mode == 10) && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
+  if (big && dk_use_v4(p, nullptr)) return dk_launch_gemm256v4(p, nullptr, stream);
   if (big) return dk_launch_gemm256v3(p, nullptr, stream);
   if (p.kn_w != nullptr) {
     // the fused key QKNorm + RoPE lives in the 256^2 kernel's tail: any other route runs the projection plain and the
@@ -309,12 +316,13 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
   if (a.ldw <= 0) a.ldw = a.K;
   if (b.ldw <= 0) b.ldw = b.K;
   const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha && a.n_split == 0 && b.n_split == 0;
-  if (g_dk_gemm_mode == -1 && same && (a.M >= 1024 || b.M >= 1024) && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
+  if ((g_dk_gemm_mode == -1 || g_dk_gemm_mode == 10) && same && (a.M >= 1024 || b.M >= 1024) && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
     // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial extra wave costs more
     // than the small separate launch) ...
     const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
     // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
     const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
+    if (((ta + 255) / 256 == (ta + tb + 255) / 256 || g_dk_gemm_mode == 10) && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
     if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);
   }
   int rc = dk_launch_gemm(a, stream);

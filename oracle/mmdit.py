@@ -169,7 +169,14 @@ class OracleMMDiT:
         self.P = prec or Prec()
         # fp8 path of the MI355X build (no reference counterpart, oracle/fp8.py): fake-quantisation applied to the INPUT of every
         # Linear of the transformer blocks (q/k/v, o_proj, fc1, fc2); the weights handed in are then the dequantised fp8 ones
-        self.aq = act_quant or (lambda x: x)
+        # ``act_quant(x)`` or, for precision-policy studies (scripts/fp8_policy_cpu.py), ``act_quant(x, site)`` with site = (block prefix,
+        # "qkv" | "o" | "fc1" | "fc2"): which Linear is about to consume x
+        if act_quant is None:
+            self.aq = lambda x, site=None: x
+        elif getattr(act_quant, "takes_site", False):
+            self.aq = act_quant
+        else:
+            self.aq = lambda x, site=None: act_quant(x)
         # FLUX.1-dev guidance strength (cfg.guidance_embed): see cache_modulation_params
         self.guidance = guidance
         self.gelu = {"erf": gelu_erf, "tanh": gelu_tanh}[gelu]  # "erf" = the MLX path (quirk Q3)
@@ -237,7 +244,7 @@ class OracleMMDiT:
         cfg, P = self.cfg, self.P
         mod = self._mod[prefix][tkey].chunk(n_mod, dim=-1)
         m = affine_transform(x, mod[0], mod[1], cfg.layer_norm_eps, P)
-        mq = self.aq(m)
+        mq = self.aq(m, (prefix, "qkv"))
         q = self._lin(mq, prefix + ".attn.q_proj")
         k = self._lin(mq, prefix + ".attn.k_proj", bias=False)  # quirk Q9
         v = self._lin(mq, prefix + ".attn.v_proj")
@@ -256,16 +263,16 @@ class OracleMMDiT:
     def _post_sdpa(self, residual, sdpa_out, inter, prefix, parallel_mlp):
         cfg, P = self.cfg, self.P
         mod = inter["mod"]
-        attn_out = self._lin(self.aq(sdpa_out), prefix + ".attn.o_proj")
+        attn_out = self._lin(self.aq(sdpa_out, (prefix, "o")), prefix + ".attn.o_proj")
         if parallel_mlp:
             # fc2 bias is zeroed on every call (mmdit.py:741-742, quirk Q8)
             h1 = self.gelu(self._lin(inter["m"], prefix + ".mlp.fc1"), P)
-            mlp_out = linear(self.aq(h1), self.w[prefix + ".mlp.fc2.weight"], None, P)
+            mlp_out = linear(self.aq(h1, (prefix, "fc2")), self.w[prefix + ".mlp.fc2.weight"], None, P)
             return P.r(residual + P.r(mod[2] * P.r(attn_out + mlp_out)))
         residual = P.r(residual + P.r(attn_out * mod[2]))
         m2 = affine_transform(residual, mod[3], mod[4], cfg.layer_norm_eps, P)
-        h1 = self.gelu(self._lin(self.aq(m2), prefix + ".mlp.fc1"), P)
-        mlp_out = self._lin(self.aq(h1), prefix + ".mlp.fc2")
+        h1 = self.gelu(self._lin(self.aq(m2, (prefix, "fc1")), prefix + ".mlp.fc1"), P)
+        mlp_out = self._lin(self.aq(h1, (prefix, "fc2")), prefix + ".mlp.fc2")
         return P.r(residual + P.r(mod[5] * mlp_out))
 
     def _merge(self, t):  # [B,H,S,D] -> [B,S,h]

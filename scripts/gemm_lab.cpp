@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
       if (dk_gemm_bf16(&d, st) != 0) { printf("  mode %d not applicable: %s\n", modes[v], dk_last_error()); skip[v] = true; continue; }
       CK(hipStreamSynchronize(st));
       CK(hipMemcpy(v == 0 ? ref.data() : got.data(), C[v], (size_t)s.M * s.N * 2, hipMemcpyDeviceToHost));
-      if (v > 0 && modes[v] < 10) {
+      if (v > 0 && modes[v] <= 10) {
         size_t bad = 0;
         double maxd = 0;
         for (size_t i = 0; i < ref.size(); ++i) {

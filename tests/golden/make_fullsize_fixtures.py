@@ -32,6 +32,14 @@ Round 4 (VERDICT r3 "Next round" item 2: full depth beyond the schedule's first 
   sd3_full_late  BASELINE configs[2] at full depth (24 blocks, B = 2, CFG 5.0, 589 text tokens): steps 1, 25, 49 and 50 of the 50-step
                  schedule the same way (late steps: small sigma, fp16-rounded timesteps 8.93 / 66.9)
 
+Round 5 (VERDICT r4 "Next round" item 2: CLOSED-LOOP runs of the 50-step configurations; error accumulation over a whole trajectory):
+  sd3_full_50    BASELINE configs[2] end to end: SD3-medium, 24 blocks, B = 2 (CFG 5.0), 589 text tokens, latent 128 x 128, ALL 50 Euler
+                 steps of the 50-step schedule, each from the latent the previous one left (fp32 oracle, ~1 h on 6 cores) -> the latent
+                 after steps 1, 3, 10, 20, 30, 40 (fp16) and 50 (fp32), and the decoded 1024 x 1024 image (fp32 oracle decode of the
+                 bf16-rounded final latent, uint8)
+  flux_dev_10    BASELINE configs[3]'s shape closed loop: 19 + 38 blocks at FLUX width, S_t = 512, a complete 10-step schedule
+                 (sigma 1 -> 0) -> the latent after steps 1, 2, 5 (fp16) and 10 (fp32); replayed with bf16 and with fp8 weights
+
 The fp32 oracle of the FLUX cases and of every round-3 case is the reference's function with fp32 ACTIVATIONS: its timestep
 embedding is still evaluated in config.dtype (mmdit.py:379-389, quirk Q2; bf16 for FLUX, fp16 for SD3) -- ``ref_model`` below.
 Round 2's FLUX fixtures used an oracle with an exact embedding and measured, at 27-32 dB, the distance between two different
@@ -108,6 +116,12 @@ FLUX_DEV_FULL = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=512, 
                      step_ids=(0, 1, 48, 49), noise_seed=0, clean_seed=91, text_seed=73, rows=1)
 SD3_FULL_LATE = dict(cfg=SD3_2b, seed_w=1234, latent=(128, 128), S_t=589, steps_of=50, shift=3.0, cfg_weight=5.0, flux=False,
                      step_ids=(0, 24, 48, 49), noise_seed=0, clean_seed=92, text_seed=81, rows=2)
+
+
+# ---- round 5 cases: closed-loop trajectories ---------------------------------------------------------------------------------------
+SD3_FULL_50 = dict(SD3_FULL_1024, n_steps=50, keep=(1, 3, 10, 20, 30, 40, 50), seed_vae=4321)
+FLUX_DEV_10 = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=512, steps=10, shift=1.0, noise_seed=0, keep=(1, 2, 5, 10),
+                   text_seed=73)
 
 
 def forced_inputs(c):
@@ -383,7 +397,67 @@ def make_flux_pair():
     return out
 
 
-CASES = {"flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
+def make_sd3_full_50():
+    """configs[2] closed loop, all 50 steps (fp32 oracle; same weights, conditioning, x0 and schedule as sd3_full_1024)"""
+    c = SD3_FULL_50
+    cfg = c["cfg"]
+    w = {k: v.float() for k, v in synth_mmdit_weights(cfg, seed=c["seed_w"]).items()}
+    text, pooled = sd3_full_inputs()
+    x0, sig = sd3_full_start(c)
+    assert len(sig) == 51 and float(sig[-1]) == 0.0
+    t0 = time.time()
+    trace = ProgressTrace("sd3_full_50", t0)
+    last = op.sample_euler(ref_model(cfg, w, Prec()), x0, sig, text, pooled, c["cfg_weight"], Prec(BF), trace, t_act=Prec(torch.float16))
+    out = {"keep": np.asarray(c["keep"])}
+    for k in c["keep"][:-1]:
+        out[f"x_step{k}_f16"] = trace[k - 1].numpy().astype(np.float16)
+    out["x_step50_fp32"] = last.numpy()
+    # the image: process_out + decode as DiffusionPipeline.decode_latents_to_image (mlx/__init__.py:576-584), fp32 oracle decoder on the
+    # bf16-rounded latent (the engine's input dtype), uint8 as generate_image returns it (:525-526)
+    del w
+    vw = {k: v.float() for k, v in synth_vae_weights(VAEDecoderConfig(), seed=c["seed_vae"]).items()}
+    z = op.process_out(last, "sd3").to(BF).float()
+    raw = OracleVAEDecoder(VAEDecoderConfig(), vw, Prec())(z)
+    img = torch.clip(raw / 2 + 0.5, 0, 1)
+    out["image_u8"] = (img[0] * 255).numpy().astype(np.uint8)
+    print(f"sd3_full_50 decode done, {time.time() - t0:.0f} s", flush=True)
+    return out
+
+
+class ProgressTrace(list):
+    def __init__(self, name, t0):
+        super().__init__()
+        self.name, self.t0 = name, t0
+
+    def append(self, x):
+        super().append(x)
+        print(f"{self.name} step {len(self)}: {time.time() - self.t0:.0f} s, rms {float(x.pow(2).mean().sqrt()):.4f}", flush=True)
+
+
+def flux_dev_10_inputs():
+    c = FLUX_DEV_10
+    text = randn(1, c["S_t"], c["cfg"].token_level_text_embed_dim, seed=c["text_seed"])
+    pooled = randn(1, c["cfg"].pooled_text_embed_dim, seed=c["text_seed"] + 1)
+    return text, pooled
+
+
+def make_flux_dev_10():
+    """configs[3]'s shape closed loop: a complete 10-step schedule through denoise_latents (fp32 oracle)"""
+    c = FLUX_DEV_10
+    cfg = c["cfg"]
+    w = LazyFloat(synth_mmdit_weights(cfg, seed=c["seed_w"]))
+    text, pooled = flux_dev_10_inputs()
+    t0 = time.time()
+    trace = ProgressTrace("flux_dev_10", t0)
+    lat = op.denoise_latents(ref_model(cfg, w, Prec()), text, pooled, c["steps"], 0.0, c["latent"], c["noise_seed"], c["shift"], True, Prec(BF),
+                             trace=trace)
+    out = {"keep": np.asarray(c["keep"]), "latent_fp32": lat.numpy()}
+    for k in c["keep"][:-1]:
+        out[f"x_step{k}_f16"] = trace[k - 1].numpy().astype(np.float16)   # sample_euler's latent (before process_out)
+    return out
+
+
+CASES = {"sd3_full_50": make_sd3_full_50, "flux_dev_10": make_flux_dev_10, "flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
          "flux_1024": lambda: make_forward(FLUX_1024, "flux_1024"), "flux_full": make_flux_full,
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,
@@ -392,7 +466,7 @@ CASES = {"flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_
          "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True)}
 
 if __name__ == "__main__":
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(int(os.environ.get("DK_FIXTURE_THREADS", os.cpu_count() or 8)))
     for name in sys.argv[1:] or list(CASES):
         t0 = time.time()
         res = CASES[name]()
