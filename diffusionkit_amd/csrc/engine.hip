@@ -39,7 +39,12 @@ int g_dk_vae_attn = 1;
 extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
-  if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
+  if (strcmp(key, "gemm") == 0) {  // (10 .. 13: gemm256v4.hip with schedule variant value - 10)
+    g_dk_gemm_mode = value >= 10 && value <= 13 ? 10 : value;
+    if (value >= 10 && value <= 13) g_dk_v4_var = value - 10;
+    return 0;
+  }
+  if (strcmp(key, "gemm_v4") == 0) { g_dk_v4_auto = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "attn_balance") == 0) { g_dk_attn_balance = value; return 0; }

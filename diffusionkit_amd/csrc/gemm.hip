@@ -234,10 +234,22 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
 // (gemm256v3.hip) on every shape it accepts, 10 = the one-wave-per-SIMD 256^2 kernel (gemm256v4.hip) on every shape IT accepts (others: 9)
 int g_dk_gemm_mode = -1;
 
-// which of the two 256^2 kernels takes a launch both accept
+// Which of the two 256^2 kernels takes a launch both accept.  gemm256v4.hip (one wave per SIMD, asm body) runs its K loop 5-7 % faster
+// (profiles/r05_gemm_v4_*.log: 8192^3 1587 against 1488 TF with cold weights, the model's linear1 / linear2 / fc1 / fc2 +4-5 %), but has no
+// remainder handling: gemm256v3.hip keeps the launches whose last round of the CUs is a small remainder (its 224-row tiles and the
+// remainder-wave K split fill those: the q / k / v projections at 2.25-2.4 rounds, the grouped image + text fc1 at 3.2).
+int g_dk_v4_auto = -1;  // dk_tune_set("gemm_v4", v): -1 (default) the rule below, 0 never in the automatic choice (A/B runs)
 static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
-  if (g_dk_gemm_mode != 10) return false;
-  return dk_gemm256v4_eligible(a) && (b == nullptr || dk_gemm256v4_eligible(*b));
+  if (g_dk_gemm_mode != 10 && (g_dk_gemm_mode != -1 || g_dk_v4_auto == 0)) return false;
+  if (!dk_gemm256v4_eligible(a) || (b != nullptr && !dk_gemm256v4_eligible(*b))) return false;
+  if (g_dk_gemm_mode == 10) return true;
+  // short reductions stay on gemm256v3.hip: this kernel's fixed cost per tile is ~1 us higher (a lone wave drains and writes out the whole
+  // 128 x 128 block), a third of a K = 1536 tile's time -- SD3-medium in the model: 21.2 against 20.3 ms per step (profiles/r05_gemm_v4_in_model.log)
+  if (a.K < 2048) return false;
+  long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
+  if (b) tiles += (long)((b->M + 255) / 256) * (b->N / 256);
+  const long frac = tiles % 256;
+  return tiles <= 256 || tiles >= 2048 || frac == 0 || frac > 144;
 }
 
 int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
@@ -322,7 +334,7 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
     const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
     // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
     const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
-    if (((ta + 255) / 256 == (ta + tb + 255) / 256 || g_dk_gemm_mode == 10) && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
+    if ((ta + 255) / 256 == (ta + tb + 255) / 256 && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
     if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);
   }
   int rc = dk_launch_gemm(a, stream);

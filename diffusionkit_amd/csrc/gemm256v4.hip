@@ -100,7 +100,36 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       for (int itr = 0; itr < 8; ++itr) ss[0][itr] = ss[1][itr] = ss[0][itr] + ss[1][itr];
     }
   }
-#pragma unroll 1
+  // FAST tiles: everything the rows read from memory is fetched before the first store -- for all four passes at once (the residual is
+  // updated in place, C == res: behind a store the compiler may not move a load up, and a lone wave has nothing else to cover the
+  // round trip; gemm256v3.hip round 4 did this per pass)
+  constexpr bool PRE_RES = FAST && (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES);
+  constexpr bool PRE_ROPE = FAST && KF;
+  uint4 res_pre[PRE_RES ? 4 : 1][PRE_RES ? 8 : 1];
+  f32x4 rope_pre[PRE_ROPE ? 4 : 1][PRE_ROPE ? 16 : 1];
+  float gate_pre[(FAST && EK == DK_EPI_GATE_RES) ? 4 : 1][8];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int wn = 2 * t.wn2 + (pass >> 1), ni = pass & 1;
+    const int col = t.n0 + wn * 64 + ni * 32 + rc2 * 4;
+    if (PRE_RES) {
+#pragma unroll
+      for (int itr = 0; itr < 8; ++itr) res_pre[pass][itr] = *(const uint4*)(p.res + (physR0 + itr * 16 + rrow) * (size_t)p.ldr + col);
+    }
+    if (FAST && EK == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate_pre[pass]);
+    if (PRE_ROPE) {
+      if (p.kn_rope != nullptr) {
+        const int kcol = col % p.kn_D;
+#pragma unroll
+        for (int itr = 0; itr < 8; ++itr) {
+          const int kpos_ = (mrow0 + itr * 16 + rrow) % p.kn_seg_len;
+          const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos_) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
+          rope_pre[pass][2 * itr] = *(const f32x4*)tab, rope_pre[pass][2 * itr + 1] = *(const f32x4*)(tab + 4);
+        }
+      }
+    }
+  }
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int vwn = pass >> 1, ni = pass & 1;
     const int wn = 2 * t.wn2 + vwn;
@@ -111,32 +140,18 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
     float kw8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int kcol = KF ? col % p.kn_D : 0;
     if (KF) unpack8(*(const uint4*)(t.nw + kcol), kw8);
-    if (FAST && ep == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate8);
+    if (FAST && EK == DK_EPI_GATE_RES) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gate8[e] = gate_pre[pass][e];
+    } else if (FAST && ep == DK_EPI_GATE_RES) {
+      unpack8(*(const uint4*)(gate_row + col), gate8);
+    }
     int c_seg = 0, c_rem = 0, r_seg = 0, r_rem = 0, g_seg = 0, g_rem = 0;
     if (!FAST) {
       const int ms = mrow0 + rrow;
       c_seg = ms / p.c_seg_len, c_rem = ms % p.c_seg_len;
       if (hres) r_seg = ms / p.r_seg_len, r_rem = ms % p.r_seg_len;
       if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
-    }
-    // FAST tiles: everything the rows read from memory is fetched before the row loop (one round trip per pass; gemm256v3.hip round 4)
-    constexpr bool PRE_RES = FAST && (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES);
-    constexpr bool PRE_ROPE = FAST && KF;
-    uint4 res_pre[PRE_RES ? 8 : 1];
-    f32x4 rope_pre[PRE_ROPE ? 16 : 1];
-    if (PRE_RES) {
-#pragma unroll
-      for (int itr = 0; itr < 8; ++itr) res_pre[itr] = *(const uint4*)(p.res + (physR0 + itr * 16 + rrow) * (size_t)p.ldr + col);
-    }
-    if (PRE_ROPE) {
-      if (p.kn_rope != nullptr) {
-#pragma unroll
-        for (int itr = 0; itr < 8; ++itr) {
-          const int kpos_ = (mrow0 + itr * 16 + rrow) % p.kn_seg_len;
-          const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos_) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
-          rope_pre[2 * itr] = *(const f32x4*)tab, rope_pre[2 * itr + 1] = *(const f32x4*)(tab + 4);
-        }
-      }
     }
 #pragma unroll
     for (int itr = 0; itr < 8; ++itr) {
@@ -169,7 +184,7 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
         if (p.kn_rope != nullptr) {
           const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
           f32x4 t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
-          if (PRE_ROPE) t0 = rope_pre[2 * itr], t1 = rope_pre[2 * itr + 1];
+          if (PRE_ROPE) t0 = rope_pre[pass][2 * itr], t1 = rope_pre[pass][2 * itr + 1];
           else if (valid) t0 = *(const f32x4*)tab, t1 = *(const f32x4*)(tab + 4);
           const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
@@ -191,7 +206,7 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
         for (int e = 0; e < 8; ++e) vv[e] = silu_f(vv[e]);
       } else if (hres) {
         uint4 rr = make_uint4(0u, 0u, 0u, 0u);
-        if (PRE_RES) rr = res_pre[itr];
+        if (PRE_RES) rr = res_pre[pass][itr];
         else if (FAST || valid) rr = *(const uint4*)(p.res + rrow_phys * (size_t)p.ldr + col);
         float r8[8];
         unpack8(rr, r8);
@@ -213,6 +228,8 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
   }
 }
 
+// VAR: schedule variant of the asm body (scripts/gen_gemm256v4.py: VARIANTS)
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(v4_lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
@@ -291,14 +308,35 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   const int nk = p.K / V4_BK;
   const float alpha = p.alpha;
 
-  asm volatile(
-#include "gemm256v4_asm.inc"
-      :
-      : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd), "{v[24:25]}"(dr),
-        "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
-      :
+#define V4_ASM_OPERANDS                                                                                                                              \
+  : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), [wave] "s"(wave), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd), \
+    "{v[24:25]}"(dr), "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
+  if constexpr (VAR == 0) {
+    asm volatile(
+#include "gemm256v4_asm0.inc"
+        : V4_ASM_OPERANDS:
 #include "gemm256v4_clobbers.inc"
-  );
+    );
+  } else if constexpr (VAR == 1) {
+    asm volatile(
+#include "gemm256v4_asm1.inc"
+        : V4_ASM_OPERANDS:
+#include "gemm256v4_clobbers.inc"
+    );
+  } else if constexpr (VAR == 2) {
+    asm volatile(
+#include "gemm256v4_asm2.inc"
+        : V4_ASM_OPERANDS:
+#include "gemm256v4_clobbers.inc"
+    );
+  } else {
+    asm volatile(
+#include "gemm256v4_asm3.inc"
+        : V4_ASM_OPERANDS:
+#include "gemm256v4_clobbers.inc"
+    );
+  }
+#undef V4_ASM_OPERANDS
 
   // ---------------- tail: staged bf16 image -> row-major, epilogues on the way ----------------
   const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
@@ -330,6 +368,8 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   }
 }
 
+int g_dk_v4_var = 0;  // schedule variant (lab: dk_tune_set("gemm", 10 + variant))
+
 // dk_tune_set("gemm", 10) forces this kernel on every shape it accepts; -1 (automatic): see dk_launch_gemm / dk_launch_gemm_pair
 bool dk_gemm256v4_eligible(const GemmParams& p) {
   if (p.conv || !dk_gemm256v3_eligible(p)) return false;
@@ -348,7 +388,10 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   }
   static DkDeviceOnce attr_once;
   if (attr_once.first()) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
     attr_once.mark();
   }
   const int tiles_a = ((p.M + 255) / 256) * (p.N / 256);
@@ -356,7 +399,13 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
-  hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b);
+  const dim3 grid(tiles_a + tiles_b), block(256);
+  switch (g_dk_v4_var) {
+    case 1: hipLaunchKernelGGL(dk_gemm256v4_kernel<1>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
+    case 2: hipLaunchKernelGGL(dk_gemm256v4_kernel<2>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
+    case 3: hipLaunchKernelGGL(dk_gemm256v4_kernel<3>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
+    default: hipLaunchKernelGGL(dk_gemm256v4_kernel<0>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
+  }
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -76,6 +76,13 @@ int main(int argc, char** argv) {
       {256, 12288, 4096, "t5 qkv (M=256)", DK_EPI_BIAS},
       {256, 4096, 10240, "t5 wo (M=256)", DK_EPI_BIAS},
       {1178, 6144, 1536, "sd3 fc1 txt", DK_EPI_BIAS_GELU},
+      // round 5: the model's exact launches that the list above only approximates
+      {4352, 21504, 3072, "flux single linear1", DK_EPI_BIAS},
+      {8192, 1536, 1536, "sd3 o", DK_EPI_GATE_RES},
+      {8192, 6144, 1536, "sd3 fc1", DK_EPI_BIAS_GELU},
+      {4608, 21504, 3072, "flux-dev linear1", DK_EPI_BIAS},
+      {4608, 3072, 15360, "flux-dev l2", DK_EPI_GATE_RES},
+      {4096, 2432, 2432, "sd3.5 o (half tile)", DK_EPI_GATE_RES},
   };
   std::vector<int> modes = {128, 5, 6, 3};
   if (getenv("LAB_MODES")) {  // e.g. LAB_MODES=128,1,11,12 (>= 10: ablation builds, not checked)
@@ -136,7 +143,7 @@ int main(int argc, char** argv) {
       if (dk_gemm_bf16(&d, st) != 0) { printf("  mode %d not applicable: %s\n", modes[v], dk_last_error()); skip[v] = true; continue; }
       CK(hipStreamSynchronize(st));
       CK(hipMemcpy(v == 0 ? ref.data() : got.data(), C[v], (size_t)s.M * s.N * 2, hipMemcpyDeviceToHost));
-      if (v > 0 && modes[v] <= 10) {
+      if (v > 0 && modes[v] <= 13) {
         size_t bad = 0;
         double maxd = 0;
         for (size_t i = 0; i < ref.size(); ++i) {

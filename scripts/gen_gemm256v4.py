@@ -89,63 +89,96 @@ def wait(vm=None, lgkm=None):
 BARRIER = lambda: I("barrier", "s_barrier")  # noqa: E731
 
 
-def body(dma_on, next_on, vm_x, vm_w):
+def body(dma_on, next_on, outstanding_next, phase=None, nbar=4):
     """one K-tile.  dma_on: issue the pieces of K-tile i + 2; next_on: read the first slice of K-tile i + 1 at the end;
-    vm_x / vm_w: vmcnt that guarantees X / W of K-tile i + 1 have landed (own pieces)."""
+    outstanding_next: own pieces of K-tile i + 1 that may still be in flight at the head of this body (16, X before W);
+    phase: None = every wave issues its DMA pieces at the same MFMA slots; w = this is wave w's copy of the body, pieces 4 slots apart
+    and shifted by w (the CU's four waves run in lockstep between barriers: pieces issued at the same slot queue up behind each other);
+    nbar: 4 = one release and one landed barrier per operand, 2 = one release and one landed barrier for both."""
     mf = [mfma(j, k, 0) for j in range(8) for k in range(8)] + [mfma(j, k, 1) for j in range(8) for k in range(8)]
     slots = [[] for _ in range(129)]  # slots[m] = instructions in front of MFMA m (128 = behind the last one)
 
     def put(m, ins):
         slots[m].extend(ins if isinstance(ins, list) else [ins])
 
-    # -- second slice of X (this tile): reads behind MFMA 0, 2, .. 14; toggles of the kk1 address registers first
+    def put_dma(m, o, g):  # (SALU write of M0 -> LDS-DMA needs one wait state: the M0 write sits one MFMA ahead of its piece)
+        a, b = dma(o, g)
+        put(m - 1, a)
+        put(m, b)
+
     put(0, I("v_xor", f"v_xor_b32 v{RX[1]}, 0x8000, v{RX[1]}", dst=RX[1], imm=0x8000))
     put(0, I("v_xor", f"v_xor_b32 v{RW[1]}, 0x8000, v{RW[1]}", dst=RW[1], imm=0x8000))
-    for k in range(8):
-        put(1 + 2 * k, ds_read(XF[1] + 4 * k, RX[1], k * 2048))
-    put(20, wait(lgkm=0))
-    put(21, BARRIER())  # every wave has read both slices of X(i): its slot is free
-    # -- second slice of W; the X pieces of K-tile i + 2 in between
-    xd = [22, 24, 26, 28, 30, 53, 55, 57]
-    if dma_on:  # (SALU write of M0 -> LDS-DMA needs one wait state: the M0 write sits one MFMA ahead of its piece)
-        for g, m in enumerate(xd):
-            put(m - 1, dma("X", g)[0])
-            put(m, dma("X", g)[1])
-    for j in range(8):
-        put(23 + 2 * j, ds_read(WF[1] + 4 * j, RW[1], j * 2048))
-    put(51, wait(lgkm=0))
-    put(52, BARRIER())  # W(i)'s slot is free
-    wd = [59, 61, 86, 88, 90, 98, 102, 124]
-    if dma_on:
-        for g, m in enumerate(wd):
-            put(m - 1, dma("W", g)[0])
-            put(m, dma("W", g)[1])
-    if next_on:
-        put(66, I("v_xor", f"v_xor_b32 v{RX[0]}, 0x8000, v{RX[0]}", dst=RX[0], imm=0x8000))
-        put(67, I("v_xor", f"v_xor_b32 v{RW[0]}, 0x8000, v{RW[0]}", dst=RW[0], imm=0x8000))
-        put(68, wait(vm=vm_x))
-        put(69, BARRIER())  # X(i + 1) has landed for every wave
+    waits = []  # (slot, operand) of the landed waits, filled in below
+    if nbar == 4:
         for k in range(8):
-            put(70 + 2 * k, ds_read(XF[0] + 4 * k, RX[0], k * 2048))
-        put(105, wait(vm=vm_w))
-        put(106, BARRIER())  # W(i + 1) has landed
+            put(1 + 2 * k, ds_read(XF[1] + 4 * k, RX[1], k * 2048))
+        put(20, wait(lgkm=0))
+        put(21, BARRIER())  # every wave has read both slices of X(i): its slot is free
         for j in range(8):
-            put(107 + j, ds_read(WF[0] + 4 * j, RW[0], j * 2048))
-    if dma_on:  # advance the K offset and flip the destination slot for the next iteration
-        put(125, I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
-        put(126, I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
-        put(127, I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
+            put(23 + 2 * j, ds_read(WF[1] + 4 * j, RW[1], j * 2048))
+        put(51, wait(lgkm=0))
+        put(52, BARRIER())  # W(i)'s slot is free
+        if dma_on:
+            if phase is None:
+                xd = [22, 24, 26, 28, 30, 53, 55, 57]
+                wd = [59, 61, 86, 88, 90, 98, 102, 124]
+            else:
+                xd = [23 + 4 * g + phase for g in range(8)]       # 23 .. 54
+                wd = [55 + 4 * g + phase for g in range(8)]       # 55 .. 86  (+3)
+            for g in range(8):
+                put_dma(xd[g], "X", g)
+                put_dma(wd[g], "W", g)
+        if next_on:
+            put(66, I("v_xor", f"v_xor_b32 v{RX[0]}, 0x8000, v{RX[0]}", dst=RX[0], imm=0x8000))
+            put(67, I("v_xor", f"v_xor_b32 v{RW[0]}, 0x8000, v{RW[0]}", dst=RW[0], imm=0x8000))
+            waits.append((68, "X"))
+            put(69, BARRIER())  # X(i + 1) has landed for every wave
+            for k in range(8):
+                put(70 + 2 * k, ds_read(XF[0] + 4 * k, RX[0], k * 2048))
+            waits.append((105, "W"))
+            put(106, BARRIER())  # W(i + 1) has landed
+            for j in range(8):
+                put(107 + j, ds_read(WF[0] + 4 * j, RW[0], j * 2048))
+    else:
+        for k in range(8):
+            put(1 + 2 * k, ds_read(XF[1] + 4 * k, RX[1], k * 2048))
+            put(2 + 2 * k, ds_read(WF[1] + 4 * k, RW[1], k * 2048))
+        put(30, wait(lgkm=0))
+        put(31, BARRIER())  # both slots of K-tile i are free
+        if dma_on:
+            ph = 0 if phase is None else phase
+            step = 2 if phase is None else 4
+            for g in range(8):
+                put_dma(33 + 2 * step * g + ph, "X", g)             # X and W pieces alternate
+                put_dma(33 + 2 * step * g + step + ph, "W", g)
+        if next_on:
+            put(94, I("v_xor", f"v_xor_b32 v{RX[0]}, 0x8000, v{RX[0]}", dst=RX[0], imm=0x8000))
+            put(95, I("v_xor", f"v_xor_b32 v{RW[0]}, 0x8000, v{RW[0]}", dst=RW[0], imm=0x8000))
+            waits.append((101, "W"))  # both operands of K-tile i + 1
+            put(102, BARRIER())
+            for k in range(8):
+                put(103 + k, ds_read(XF[0] + 4 * k, RX[0], k * 2048))
+                put(111 + k, ds_read(WF[0] + 4 * k, RW[0], k * 2048))
+    if dma_on:  # advance the K offset and flip the destination slot for the next iteration (behind the last piece)
+        put(128, I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
+        put(128, I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
+        put(128, I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
+    # the landed waits: pieces of K-tile i + 2 issued so far in program order may stay in flight; for the X wait W(i + 1)'s 8 as well
+    for m, o in waits:
+        issued = sum(1 for mm in range(m + 1) for ins in slots[mm] if ins.op == "dma")
+        keep = issued + (8 if (o == "X" and outstanding_next == 16) else 0)
+        slots[m].append(wait(vm=keep))
     out = []
     for m in range(128):
         out.extend(slots[m])
         out.append(mf[m])
     out.extend(slots[128])
     if next_on:
-        out.append(wait(lgkm=0))  # the first slice of the next K-tile, issued >= 13 MFMAs ago
+        out.append(wait(lgkm=0))  # the first slice of the next K-tile
     return out
 
 
-def program():
+def program(nbar=4, stagger=False):
     P = []
     # ---- inputs -> working registers
     for d, s in ((RX[0], 16), (RX[1], 17), (RW[0], 18), (RW[1], 19)):
@@ -156,29 +189,35 @@ def program():
     P.append(I("s_add", f"s_add_u32 s71, s70, {W_BASE}", dst=71, a=70, imm=W_BASE))
     P.append(I("s_mov", "s_mov_b32 s72, %[alpha]", dst=72, src="alpha"))
     P.append(I("s_mov", "s_mov_b32 s73, %[alpha]", dst=73, src="alpha"))
-    # ---- prologue: K-tile 0 into slot 0, K-tile 1 (if any) into slot 1
+
     def pro_dma(o, g):
         a, b = dma(o, g)
         return [a, I("nop", "s_nop 0"), b]
+
+    def advance():
+        return [I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128),
+                I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000),
+                I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000)]
+    # ---- prologue: K-tile 0 into slot 0, K-tile 1 (if any) into slot 1; the accumulators are zeroed while the pieces fly
     for g in range(8):
         P.extend(pro_dma("X", g))
     for g in range(8):
         P.extend(pro_dma("W", g))
     P.append(I("s_cmp_eq", "s_cmp_eq_u32 s69, 1", a=69, imm=1))
     P.append(I("cbranch_scc1", "s_cbranch_scc1 10f", target="L10"))
-    P.append(I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
-    P.append(I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
-    P.append(I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
+    P.extend(advance())
     for g in range(8):
         P.extend(pro_dma("X", g))
     for g in range(8):
         P.extend(pro_dma("W", g))
-    P.append(I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
-    P.append(I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
-    P.append(I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
+    P.extend(advance())
+    for a in range(256):
+        P.append(I("acc_write", f"v_accvgpr_write_b32 a{a}, 0", dst=a))
     P.append(wait(vm=16))
     P.append(I("branch", "s_branch 11f", target="L11"))
     P.append(I("label", "10:", name="L10"))
+    for a in range(256):
+        P.append(I("acc_write", f"v_accvgpr_write_b32 a{a}, 0", dst=a))
     P.append(wait(vm=0))
     P.append(I("label", "11:", name="L11"))
     P.append(BARRIER())
@@ -190,24 +229,35 @@ def program():
         P.append(ds_read(XF[0] + 4 * k, RX[0], k * 2048))
     for j in range(8):
         P.append(ds_read(WF[0] + 4 * j, RW[0], j * 2048))
-    for a in range(256):
-        P.append(I("acc_write", f"v_accvgpr_write_b32 a{a}, 0", dst=a))
     P.append(wait(lgkm=0))
-    # ---- K loop: nk - 2 full bodies, then the K-tile that issues no DMA, then the last one
-    P.append(I("s_cmp_lt", "s_cmp_lt_u32 s69, 3", a=69, imm=3))
-    P.append(I("cbranch_scc1", "s_cbranch_scc1 21f", target="L21"))
-    P.append(I("label", "20:", name="L20"))
-    P.extend(body(True, True, 18, 15))
-    P.append(I("s_sub", "s_sub_u32 s69, s69, 1", dst=69, a=69, imm=1))
-    P.append(I("s_cmp_gt", "s_cmp_gt_u32 s69, 2", a=69, imm=2))
-    P.append(I("cbranch_scc1", "s_cbranch_scc1 20b", target="L20"))
-    P.append(I("label", "21:", name="L21"))
-    P.append(I("s_cmp_lt", "s_cmp_lt_u32 s69, 2", a=69, imm=2))
-    P.append(I("cbranch_scc1", "s_cbranch_scc1 22f", target="L22"))
-    P.extend(body(False, True, 8, 0))
-    P.append(I("label", "22:", name="L22"))
-    P.extend(body(False, False, 0, 0))
-    # ---- drain: bf16(alpha * acc + bias) into the staging image (every wave is past the last body's second barrier: ring free)
+    # ---- K loop: nk - 2 full bodies, then the K-tile that issues no DMA, then the last one.  stagger: one copy of the loop per wave
+    copies = [None] if not stagger else [0, 1, 2, 3]
+    if stagger:
+        for w in (1, 2, 3):
+            P.append(I("s_cmp_eq", f"s_cmp_eq_u32 %[wave], {w}", a="wave", imm=w))
+            P.append(I("cbranch_scc1", f"s_cbranch_scc1 {100 + w * 10}f", target=f"W{w}"))
+    for w in copies:
+        c = 0 if w is None else w
+        L = lambda n: 100 + c * 10 + n  # noqa: E731
+        if w is not None:
+            P.append(I("label", f"{L(0)}:", name=f"W{c}"))
+        P.append(I("s_cmp_lt", "s_cmp_lt_u32 s69, 3", a=69, imm=3))
+        P.append(I("cbranch_scc1", f"s_cbranch_scc1 {L(2)}f", target=f"L21_{c}"))
+        P.append(I("label", f"{L(1)}:", name=f"L20_{c}"))
+        P.extend(body(True, True, 16, w, nbar))
+        P.append(I("s_sub", "s_sub_u32 s69, s69, 1", dst=69, a=69, imm=1))
+        P.append(I("s_cmp_gt", "s_cmp_gt_u32 s69, 2", a=69, imm=2))
+        P.append(I("cbranch_scc1", f"s_cbranch_scc1 {L(1)}b", target=f"L20_{c}"))
+        P.append(I("label", f"{L(2)}:", name=f"L21_{c}"))
+        P.append(I("s_cmp_lt", "s_cmp_lt_u32 s69, 2", a=69, imm=2))
+        P.append(I("cbranch_scc1", f"s_cbranch_scc1 {L(3)}f", target=f"L22_{c}"))
+        P.extend(body(False, True, 16, w, nbar))
+        P.append(I("label", f"{L(3)}:", name=f"L22_{c}"))
+        P.extend(body(False, False, 0, w, nbar))
+        if w is not None and w != copies[-1]:
+            P.append(I("branch", "s_branch 90f", target="DRAIN"))
+    P.append(I("label", "90:", name="DRAIN"))
+    # ---- drain: bf16(alpha * acc + bias) into the staging image (every wave is past the last body's release barrier(s): ring free)
     P.append(BARRIER())
     t = 32  # temporaries v[32:..] (the fragment registers are dead)
     n = 0
@@ -230,24 +280,27 @@ def program():
     return P
 
 
+VARIANTS = [(4, False), (4, True), (2, False), (2, True)]  # (barriers per K-tile, per-wave DMA phase)
+
 CLOBBERS = [f"v{i}" for i in range(20, 24)] + [f"v{i}" for i in range(32, 160)] + [f"a{i}" for i in range(256)] + \
            [f"s{i}" for i in range(68, 74)] + ["m0", "scc", "memory"]
 
 
 def emit(path):
-    P = program()
-    lines = []
-    for ins in P:
-        lines.append('    "' + ins.text + '\\n"')
-    n_mfma = sum(1 for i in P if i.op == "mfma")
-    with open(path, "w") as f:
-        f.write("// GENERATED by scripts/gen_gemm256v4.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
-        f.write(f"// {len(P)} instructions, {n_mfma} MFMAs (3 K-tile bodies), explicit registers: see the script's header.\n")
-        f.write("\n".join(lines) + "\n")
+    progs = []
+    for v, (nbar, stagger) in enumerate(VARIANTS):
+        P = program(nbar, stagger)
+        progs.append(P)
+        n_mfma = sum(1 for i in P if i.op == "mfma")
+        with open(path.replace("_asm.inc", f"_asm{v}.inc"), "w") as f:
+            f.write("// GENERATED by scripts/gen_gemm256v4.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
+            f.write(f"// variant {v}: {nbar} barriers per K-tile, {'one loop copy per wave with its own DMA slots' if stagger else 'one loop for all waves'}; "
+                    f"{len(P)} instructions, {n_mfma} MFMAs; explicit registers: see the script's header.\n")
+            f.write("\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n")
     with open(path.replace("_asm.inc", "_clobbers.inc"), "w") as f:
         f.write("// GENERATED by scripts/gen_gemm256v4.py\n")
         f.write(", ".join('"' + c + '"' for c in CLOBBERS) + "\n")
-    return P
+    return progs
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -314,7 +367,7 @@ def run(P, nk, late, order, seed=0, verbose=False):
         for nf8 in range(8):
             for e in range(4):
                 wv.V[BIAS0 + nf8 * 4 + e] = bias[wn2 * 128 + nf8 * 16 + 4 * q + e].view(np.uint32)
-        wv.S = {"koff": 0, "nk": nk, "dstx": w * 4096, "alpha": int(np.float32(alpha).view(np.uint32))}
+        wv.S = {"koff": 0, "nk": nk, "dstx": w * 4096, "alpha": int(np.float32(alpha).view(np.uint32)), "wave": w}
         waves.append(wv)
 
     def land_all(wv, keep):
@@ -469,13 +522,15 @@ if __name__ == "__main__":
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "diffusionkit_amd", "csrc", "gemm256v4_asm.inc")
-    P = emit(path)
-    print(f"wrote {path}: {len(P)} instructions")
+    progs = emit(path)
+    print(f"wrote {len(progs)} variants next to {path}: {[len(P) for P in progs]} instructions")
     if "--check" in sys.argv:
         allok = True
-        for nk in (1, 2, 3, 4, 5):
-            for late in (True, False):
-                for order in (0, 1):
-                    allok &= run(P, nk, late, order, seed=nk, verbose=True)
+        for v, P in enumerate(progs):
+            for nk in (1, 2, 3, 4, 6):
+                for late in (True, False):
+                    for order in (0, 1):
+                        allok &= run(P, nk, late, order, seed=nk, verbose="-v" in sys.argv)
+            print(f"variant {v}: {'ok' if allok else 'FAILED'}", flush=True)
         print("ALL OK" if allok else "FAILED")
         sys.exit(0 if allok else 1)
