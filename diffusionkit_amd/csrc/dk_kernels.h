@@ -65,7 +65,6 @@ size_t dk_gemm_split_workspace_bytes();
 bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 128 == 0, K % 64 == 0, any M, any row-segment maps
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 // gemm256v4.hip: one wave per SIMD, 256 accumulators in AGPRs, hand-scheduled asm body (N % 256 == 0, no conv / K split / half tiles)
-extern int g_dk_v4_var;
 extern int g_dk_v4_auto;  // gemm.hip
 bool dk_gemm256v4_eligible(const GemmParams& p);
 int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
@@ -154,25 +153,21 @@ struct AttnParams {
   int qn_split = 0;
   float qn_eps = 1e-6f;
   const float* q_rope = nullptr;
-  // optional hand-off workspace of the balanced form of dk_attn3_fwd_kernel (attention3.hip): dk_attention_balance_workspace_bytes()
-  // bytes = one slot per CU, then 4 KiB of flags that are zero before the first launch (the kernels leave them zero)
+  // lab only: trace buffer of attention4.hip's DK4_TRACE builds (scripts/attn_trace.py)
   void* bal_ws = nullptr;
-  unsigned* bal_flags = nullptr;
   // optional MX-fp8 copy of the output (fp8_linears: the o-projection's activation operand): row (b*S + s) of O8 at o8_ld bytes
   // per row, head h at byte column h*D; E8M0 scales of 32-column blocks in O8_scales (dk_mx_scale_index over o8_nblk 128-row
-  // blocks).  dk_attn3_fwd_kernel writes it INSTEAD of O from its accumulators (values rounded to bf16 first, as the separate
+  // blocks).  dk_attn4_fwd_kernel writes it INSTEAD of O from its accumulators (values rounded to bf16 first, as the separate
   // quantiser pass over O sees them); for the other kernels dk_launch_attention runs that pass behind the launch.
   unsigned char* O8 = nullptr;
   unsigned char* O8_scales = nullptr;
   int o8_ld = 0, o8_nblk = 0;
 };
-size_t dk_attention_balance_workspace_bytes();
-void dk_set_attention_workspace(void* ws);  // attention.hip: thread-local, picked up by dk_launch_attention
+void dk_set_attention_workspace(void* ws);  // attention.hip: thread-local lab trace buffer, picked up by dk_launch_attention
 void* dk_get_attention_workspace();
-extern int g_dk_attn_balance;
+extern int g_dk_attn_mode;
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
-int dk_launch_attention3(const AttnParams& p, int waves, hipStream_t stream);  // attention3.hip (two tiles in flight per wave; no score bias)
 int dk_launch_attention4(const AttnParams& p, hipStream_t stream);             // attention4.hip (the waves of a SIMD in opposite phases; D = 128, no score bias)
 
 // ---- single-head D = 512 attention of the VAE's mid block (attention512.hip) -------------------------------

@@ -33,28 +33,19 @@ int g_dk_pitch_min_k = 8192;
 // stages with fewer than 256 output channels use it -- the 256 / 512-channel convs are ~7 % slower than on the 256 x 256 implicit-GEMM
 // kernel, but lose their GroupNorm-apply passes), 2 only below 256 output channels, 0 never
 int g_dk_conv_halo = -1;
-// dk_tune_set("vae_attn", v): the mid block's attention (512 channels) on the flash kernel of attention512.hip (1, default) or in the
-// reference's materialised form -- scores GEMM, row softmax, transpose, P.V GEMM (0)
-int g_dk_vae_attn = 1;
 extern "C" int32_t dk_weight_pitch(int32_t k) { return k >= g_dk_pitch_min_k ? k + 64 : k; }
 extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
-  if (strcmp(key, "gemm") == 0) {  // (10 .. 13: gemm256v4.hip with schedule variant value - 10)
-    g_dk_gemm_mode = value >= 10 && value <= 13 ? 10 : value;
-    if (value >= 10 && value <= 13) g_dk_v4_var = value - 10;
-    return 0;
-  }
+  if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "gemm_v4") == 0) { g_dk_v4_auto = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
-  if (strcmp(key, "attn_balance") == 0) { g_dk_attn_balance = value; return 0; }
   if (strcmp(key, "gemm_fuse_k") == 0) { g_dk_fuse_k = value; return 0; }
   if (strcmp(key, "gemm_fuse_q") == 0) { g_dk_fuse_qg = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   if (strcmp(key, "conv_halo") == 0) { g_dk_conv_halo = value; return 0; }
-  if (strcmp(key, "vae_attn") == 0) { g_dk_vae_attn = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }
@@ -108,10 +99,13 @@ static int conv3x3_launch(const dk_conv_desc* d, void* workspace, hipStream_t st
 }
 extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) { return conv3x3_launch(d, nullptr, S_(stream)); }
 
-extern "C" size_t dk_attention_workspace_bytes(void) { return dk_attention_balance_workspace_bytes(); }
+// Round 5: the balanced launch these two served (pipelined D = 128 kernel, one workgroup per CU with a hand-off workspace) moved to
+// profiles/lab_kernels/attention3_pipelined.hip -- no default path took it (+6 % isolated, 0 inside the model).  The entry points stay for
+// ABI stability: no attention kernel of the library needs a workspace (0 bytes); a buffer handed in is only used by lab trace builds.
+extern "C" size_t dk_attention_workspace_bytes(void) { return 0; }
 extern "C" int dk_attention_set_workspace(void* workspace, size_t bytes) {
-  DK_REQUIRE(workspace == nullptr || (bytes >= dk_attention_balance_workspace_bytes() && ((uintptr_t)workspace & 255) == 0),
-             "attention workspace: dk_attention_workspace_bytes() bytes, 256-byte aligned (or NULL)");
+  DK_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 255) == 0, "attention workspace: 256-byte aligned (or NULL)");
+  (void)bytes;
   dk_set_attention_workspace(workspace);
   return 0;
 }
@@ -439,7 +433,6 @@ struct dk_mmdit {
   bool ctx_ready = false;
   int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_gemm_split_workspace_bytes()
-  void* AWS = nullptr;  // hand-off workspace of the balanced attention launch (slots + flags), dk_attention_balance_workspace_bytes()
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
   // guidance embedding (cfg.guidance_embed): MLPEmbedder weights, the value set by dk_mmdit_set_guidance, scratch rows
@@ -655,7 +648,6 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
   m->GWS = c.take(dk_gemm_split_workspace_bytes());
-  m->AWS = c.take(dk_attention_balance_workspace_bytes());
   return c.off;
 }
 
@@ -698,7 +690,6 @@ extern "C" int dk_mmdit_prepare(dk_mmdit* m, int32_t batch, int32_t latent_h, in
   }
   // the flag region of the GEMM split workspace must be zero before the first launch (the kernels leave it zero)
   DK_CHECK_HIP(hipMemsetAsync((char*)m->GWS + dk_gemm_split_workspace_bytes() - 4096, 0, 4096, st));
-  DK_CHECK_HIP(hipMemsetAsync((char*)m->AWS + dk_attention_balance_workspace_bytes() - 4096, 0, 4096, st));
   m->prepared = true;
   m->mod_ready = false;
   m->ctx_ready = false;
@@ -935,11 +926,9 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
   return 0;
 }
 
-struct MmditCallScope {  // an engine call's GEMM splits and attention hand-offs go through THAT engine's regions; the caller's settings come back
+struct MmditCallScope {  // an engine call's GEMM splits go through THAT engine's region; the caller's setting comes back
   LinearWsScope lin;
-  void* prev_attn;
-  explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS), prev_attn(dk_get_attention_workspace()) { dk_set_attention_workspace(m->AWS); }
-  ~MmditCallScope() { dk_set_attention_workspace(prev_attn); }
+  explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS) {}
 };
 
 // The transformer blocks [first, first + count) of the global order (double blocks 0 .. depth_multimodal - 1, then single blocks)
@@ -1173,7 +1162,7 @@ static size_t vae_carve(dk_vae* v, Carver& c, int B, int h, int w) {
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vt = (bf16_t*)c.take((size_t)B * align_up(tok, 64) * Cm * 2);  // (the flash form transposes every image's V up front)
   // the materialised score matrix of the general path; a 512-channel mid block runs the flash kernel (attention512.hip) and needs none
-  v->SCORES = (bf16_t*)c.take((Cm == 512 && g_dk_vae_attn != 0) ? 0 : tok * align_up(tok, 64) * 2);
+  v->SCORES = (bf16_t*)c.take(Cm == 512 ? 0 : tok * align_up(tok, 64) * 2);
   {
     // statistics scratch: up to 1024 chunk partials per batch row from the stand-alone pass, or one per 16 x 16 output tile of the
     // largest stage from the fused convs, + mean / rstd
@@ -1305,7 +1294,7 @@ struct VaeRun {
     DK_TRY(linear_plain(v->T1, kw, kb, v->Kb, B * T, C, C, DK_EPI_BIAS, st));
     DK_TRY(linear_plain(v->T1, vw, vb, v->Vb, B * T, C, C, DK_EPI_BIAS, st));
     const float scale = 1.0f / sqrtf((float)C);
-    if (g_dk_vae_attn != 0 && C == 512) {
+    if (C == 512) {
       // flash form (attention512.hip): no [T, T] score matrix
       DK_TRY(attention_d512(v->Qb, v->Kb, v->Vb, v->Y, B, T, C, C, scale, v->Vt, st));
       return linear_call(v->Y, C, B * T, 0, ow, ob, out, C, B * T, 0, B * T, C, C, DK_EPI_RES, nullptr, 0, 0, x, C, B * T, 0, st);
@@ -1435,7 +1424,7 @@ static size_t vae_carve_encoder(dk_vae* v, Carver& c, int B, int H, int W) {
   v->Vb = (bf16_t*)c.take((size_t)B * tok * Cm * 2);
   v->Vt = (bf16_t*)c.take((size_t)B * align_up(tok, 64) * Cm * 2);  // (the flash form transposes every image's V up front)
   // the materialised score matrix of the general path; a 512-channel mid block runs the flash kernel (attention512.hip) and needs none
-  v->SCORES = (bf16_t*)c.take((Cm == 512 && g_dk_vae_attn != 0) ? 0 : tok * align_up(tok, 64) * 2);
+  v->SCORES = (bf16_t*)c.take(Cm == 512 ? 0 : tok * align_up(tok, 64) * 2);
   {
     const size_t tiles = ((size_t)H / 16) * ((size_t)W / 16);
     const size_t npart = tiles > 1024 ? tiles : 1024;

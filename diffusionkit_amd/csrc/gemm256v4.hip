@@ -228,8 +228,6 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
   }
 }
 
-// VAR: schedule variant of the asm body (scripts/gen_gemm256v4.py: VARIANTS)
-template <int VAR>
 __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(v4_lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
@@ -308,35 +306,14 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   const int nk = p.K / V4_BK;
   const float alpha = p.alpha;
 
-#define V4_ASM_OPERANDS                                                                                                                              \
-  : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), [wave] "s"(wave), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd), \
-    "{v[24:25]}"(dr), "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
-  if constexpr (VAR == 0) {
-    asm volatile(
-#include "gemm256v4_asm0.inc"
-        : V4_ASM_OPERANDS:
+  asm volatile(
+#include "gemm256v4_asm.inc"
+      :
+      : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), [wave] "s"(wave), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd),
+        "{v[24:25]}"(dr), "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
+      :
 #include "gemm256v4_clobbers.inc"
-    );
-  } else if constexpr (VAR == 1) {
-    asm volatile(
-#include "gemm256v4_asm1.inc"
-        : V4_ASM_OPERANDS:
-#include "gemm256v4_clobbers.inc"
-    );
-  } else if constexpr (VAR == 2) {
-    asm volatile(
-#include "gemm256v4_asm2.inc"
-        : V4_ASM_OPERANDS:
-#include "gemm256v4_clobbers.inc"
-    );
-  } else {
-    asm volatile(
-#include "gemm256v4_asm3.inc"
-        : V4_ASM_OPERANDS:
-#include "gemm256v4_clobbers.inc"
-    );
-  }
-#undef V4_ASM_OPERANDS
+  );
 
   // ---------------- tail: staged bf16 image -> row-major, epilogues on the way ----------------
   const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
@@ -368,8 +345,6 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   }
 }
 
-int g_dk_v4_var = 0;  // schedule variant (lab: dk_tune_set("gemm", 10 + variant))
-
 // dk_tune_set("gemm", 10) forces this kernel on every shape it accepts; -1 (automatic): see dk_launch_gemm / dk_launch_gemm_pair
 bool dk_gemm256v4_eligible(const GemmParams& p) {
   if (p.conv || !dk_gemm256v3_eligible(p)) return false;
@@ -388,10 +363,7 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   }
   static DkDeviceOnce attr_once;
   if (attr_once.first()) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
     attr_once.mark();
   }
   const int tiles_a = ((p.M + 255) / 256) * (p.N / 256);
@@ -399,13 +371,7 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
-  const dim3 grid(tiles_a + tiles_b), block(256);
-  switch (g_dk_v4_var) {
-    case 1: hipLaunchKernelGGL(dk_gemm256v4_kernel<1>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
-    case 2: hipLaunchKernelGGL(dk_gemm256v4_kernel<2>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
-    case 3: hipLaunchKernelGGL(dk_gemm256v4_kernel<3>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
-    default: hipLaunchKernelGGL(dk_gemm256v4_kernel<0>, grid, block, V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b); break;
-  }
+  hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -183,20 +183,9 @@ def conv3x3_gn(x: Tensor, w: Tensor, bias: Tensor, gn_table: Optional[Tensor] = 
     return out
 
 
-_attn_ws = {}
-
-
-def attention_workspace(device) -> Tensor:
-    """Zero-initialised hand-off workspace of the balanced attention launch (dk_attention_workspace_bytes), one per device."""
-    key = str(device)
-    if key not in _attn_ws:
-        _attn_ws[key] = torch.zeros(_lib.load().dk_attention_workspace_bytes(), dtype=torch.uint8, device=device)
-    return _attn_ws[key]
-
-
 def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None, workspace: Optional[Tensor] = None) -> Tensor:
-    """SDPA over a token-major [B, S, 3*H*D] projection buffer -> [B, S, H*D].  ``workspace`` (attention_workspace): lets the
-    kernel run its balanced form (dk_attention_set_workspace for the duration of the call)."""
+    """SDPA over a token-major [B, S, 3*H*D] projection buffer -> [B, S, H*D].  ``workspace``: lab only (trace buffer of attention4.hip's
+    DK4_TRACE builds, dk_attention_set_workspace for the duration of the call)."""
     lib = _lib.load()
     _require_cuda(qkv, "qkv", BF)
     B, S, ld = qkv.shape

@@ -135,12 +135,9 @@ int dk_groupnorm_table_bf16(const void* x, int32_t B, int64_t HW, int32_t C, int
 int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
                       int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, void* stream);
 
-/* Optional hand-off workspace for dk_attention_bf16 launches of THIS host thread: with it and dk_tune_set("attn_balance", 1),
- * long-sequence D = 128 launches run in a balanced form (one workgroup per CU over equal shares of the (query block, key tile)
- * space; a split block's two halves meet through a workspace slot) -- opt-in: it gains 4-7 % on an isolated launch whose
- * workgroups fill 1.6 rounds of the CUs and nothing inside the model.  dk_attention_workspace_bytes()
- * bytes, 256-byte aligned, whose LAST 4096 bytes are zero before the first use (the kernels leave them zero); NULL switches the
- * balanced form off.  One launch at a time may use a given workspace.  The engines carry their own (dk_mmdit_workspace_bytes). */
+/* Kept for ABI stability (round 5): the balanced launch of the pipelined long-sequence kernel that used a hand-off workspace moved
+ * to profiles/lab_kernels/ -- no default path took it.  dk_attention_workspace_bytes() is 0; dk_attention_set_workspace accepts a
+ * 256-byte aligned buffer (or NULL) for THIS host thread and only lab trace builds of the attention kernel look at it. */
 size_t dk_attention_workspace_bytes(void);
 int dk_attention_set_workspace(void* workspace, size_t bytes);
 
@@ -385,12 +382,12 @@ int dk_profile_enable(int32_t on);
 int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops, int64_t* launches);
 
 /* Tuning knobs for A/B measurements (no reference counterpart); -1 = automatic (the shipped default) for every key.
- * "gemm": 128 = 128x128 tiles only, 9 = 256x256 tiles on every shape they accept; "gemm_mf": 8 / 7 = 256- / 224-row tiles;
- * "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
+ * "gemm": 128 = 128x128 tiles only, 9 = the 8-wave 256x256 kernel on every shape it accepts, 10 = the one-wave-per-SIMD 256x256 kernel
+ * (asm body) on every shape IT accepts; "gemm_v4": 0 = the automatic choice never takes the latter; "gemm_mf": 8 / 7 = 256- / 224-row
+ * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
- * 7 pipelined kernel, 9 phase-alternating kernel; 7 and 9 exist for head_dim 128 and fall back to 4 otherwise);
- * "attn_balance": 1 = balanced launch of kernel 7 (needs dk_attention_set_workspace); "attn_fuse_q": 0 = stand-alone query
- * QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form; "vae_attn": 0 = VAE mid-block attention through a materialised score matrix instead of the flash kernel;
+ * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise); "attn_fuse_q": 0 = stand-alone query
+ * QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form;
  * "pitch_min_k": rows of at least this many elements are stored padded (dk_weight_pitch).
  * Returns 0, or -1 for an unknown key. */
 int dk_tune_set(const char* key, int32_t value);

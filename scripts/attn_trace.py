@@ -13,7 +13,7 @@ from diffusionkit_amd import ops
 dev = torch.device("cuda", 0)
 B, H, S, D = 1, 24, 4352, 128
 qkv = torch.randn(B, S, 3 * H * D, device=dev).to(torch.bfloat16)
-ws = ops.attention_workspace(dev)
+ws = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)  # trace buffer (8 waves x 64 stamps)
 ops.tune("attn", 9)
 for _ in range(3):
     ws.zero_()

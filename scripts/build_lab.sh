@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_lab/obj
-for f in gemm gemm256v3 gemm256v4 gemm256f8 fp8_ops attention attention2 attention3 attention512 elementwise vae_ops conv_halo text_ops profile engine; do
+for f in gemm gemm256v3 gemm256v4 gemm256f8 fp8_ops attention attention2 attention4 attention512 elementwise vae_ops conv_halo text_ops profile engine; do
   EXTRA=""; [ "$f" = attention2 ] && EXTRA="-fno-honor-nans"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDK_LAB_ABLATIONS $EXTRA -c diffusionkit_amd/csrc/$f.hip -o build_lab/obj/$f.o &
 done

@@ -25,7 +25,7 @@ from diffusionkit_amd.weights import synth_mmdit_weights  # noqa: E402
 from oracle import fp8 as o8  # noqa: E402
 from oracle.mmdit import OracleMMDiT, Prec, embed_dtype  # noqa: E402
 
-DM, DU = 4, 8
+DM, DU = (19, 38) if os.environ.get("FP8_POLICY_FULL") else (4, 8)
 CFG = replace(FLUX_SCHNELL, depth_multimodal=DM, depth_unified=DU)
 C = dict(cfg=CFG, seed_w=1234, B=1, latent=(128, 128), S_t=512, timesteps=[1000.0, 752.0], step=1)
 
@@ -40,8 +40,15 @@ def cls_double(stream, site):
     return lambda p, s: block_of(p)[0].startswith("multimodal") and block_of(p)[2].startswith(stream) and s == site
 
 
+def first_doubles(n):
+    return lambda p, s: block_of(p)[0].startswith("multimodal") and block_of(p)[1] < n
+
+
 CLASSES = {
     "none (all fp8)": lambda p, s: False,
+    "first 2 double blocks": first_doubles(2),
+    "D.img MLP (fc1 + fc2)": lambda p, s: block_of(p)[0].startswith("multimodal") and block_of(p)[2].startswith("image") and s in ("fc1", "fc2"),
+    "first 4 double blocks": first_doubles(4),
     "D.img.qkv": cls_double("image", "qkv"), "D.img.o": cls_double("image", "o"), "D.img.fc1": cls_double("image", "fc1"),
     "D.img.fc2": cls_double("image", "fc2"),
     "D.txt (all four)": lambda p, s: block_of(p)[0].startswith("multimodal") and block_of(p)[2].startswith("text"),
@@ -99,7 +106,10 @@ def main():
     ref = run(plain, None)
     print(f"fp32 oracle, un-quantised: {time.time() - t0:.0f} s", flush=True)
     rows = []
+    only = os.environ.get("FP8_POLICY_ONLY")
     for name, keep in CLASSES.items():
+        if only and not any(name.startswith(o) for o in only.split("|")):
+            continue
         t0 = time.time()
         if keep == "act_off":
             w, aq, share = fq_all, None, float("nan")

@@ -6,7 +6,8 @@ in AGPRs a[0:255], and the whole main body -- prologue DMA, K loop, the two peel
 into the bf16 staging image -- is one inline-asm block with the register file addressed by hand.  This script writes that block
 (gemm256v4_asm.inc, a C string literal) from an instruction list, and checks the SAME list on the CPU first:
 
-  python scripts/gen_gemm256v4.py            write diffusionkit_amd/csrc/gemm256v4_asm.inc
+  python scripts/gen_gemm256v4.py            write diffusionkit_amd/csrc/gemm256v4_asm.inc (the shipped schedule, VARIANTS[0])
+  python scripts/gen_gemm256v4.py --lab      also write the measured-and-dropped schedule variants to profiles/lab_kernels/gemm256v4_variants/
   python scripts/gen_gemm256v4.py --check    also run the instruction-level emulator (4 waves x 64 lanes, numpy) on one 256 x 256 tile:
                                              every LDS-DMA piece lands at the LATEST moment its vmcnt wait allows (or at issue), every
                                              ds_read delivers at its lgkmcnt wait (or at issue), waves run in both orders between barriers
@@ -28,6 +29,7 @@ Register map (per lane)              LDS (bytes)
   v[160:191] bias of the lane's 32 columns (in)
   s[60:63] X resource  s[64:67] W resource (in);  s68 K byte offset  s69 K-tiles left  s70 / s71 DMA destination bases  s[72:73] alpha
 """
+import os
 import sys
 
 import numpy as np
@@ -280,19 +282,25 @@ def program(nbar=4, stagger=False):
     return P
 
 
-VARIANTS = [(4, False), (4, True), (2, False), (2, True)]  # (barriers per K-tile, per-wave DMA phase)
+# (barriers per K-tile, per-wave DMA phase).  VARIANTS[0] ships.  Measured (profiles/r05_gemm_v4_lab_variants.log, r05_gemm_v4_blas_cold.log): with
+# weights that come from HBM -- every launch of the model -- variant 0 is the fastest on every shape; variant 3 (pieces staggered per wave, two
+# barriers) wins by 1-5 % only when the weights are L2 / Infinity-Cache resident, variant 2 shows what un-staggered pieces cost there (-8 %)
+VARIANTS = [(4, False), (4, True), (2, False), (2, True)]
 
 CLOBBERS = [f"v{i}" for i in range(20, 24)] + [f"v{i}" for i in range(32, 160)] + [f"a{i}" for i in range(256)] + \
            [f"s{i}" for i in range(68, 74)] + ["m0", "scc", "memory"]
 
 
-def emit(path):
+def emit(path, lab_dir=None):
     progs = []
     for v, (nbar, stagger) in enumerate(VARIANTS):
         P = program(nbar, stagger)
         progs.append(P)
+        if v > 0 and lab_dir is None:
+            continue
         n_mfma = sum(1 for i in P if i.op == "mfma")
-        with open(path.replace("_asm.inc", f"_asm{v}.inc"), "w") as f:
+        out = path if v == 0 else os.path.join(lab_dir, f"gemm256v4_asm{v}.inc")
+        with open(out, "w") as f:
             f.write("// GENERATED by scripts/gen_gemm256v4.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
             f.write(f"// variant {v}: {nbar} barriers per K-tile, {'one loop copy per wave with its own DMA slots' if stagger else 'one loop for all waves'}; "
                     f"{len(P)} instructions, {n_mfma} MFMAs; explicit registers: see the script's header.\n")
@@ -522,8 +530,11 @@ if __name__ == "__main__":
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "diffusionkit_amd", "csrc", "gemm256v4_asm.inc")
-    progs = emit(path)
-    print(f"wrote {len(progs)} variants next to {path}: {[len(P) for P in progs]} instructions")
+    lab = os.path.join(root, "profiles", "lab_kernels", "gemm256v4_variants") if "--lab" in sys.argv else None
+    if lab:
+        os.makedirs(lab, exist_ok=True)
+    progs = emit(path, lab)
+    print(f"wrote {path} ({len(progs[0])} instructions)" + (f" and {len(progs) - 1} lab variants under {lab}" if lab else ""))
     if "--check" in sys.argv:
         allok = True
         for v, P in enumerate(progs):

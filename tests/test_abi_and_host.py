@@ -159,12 +159,13 @@ def test_tune_keys_and_workspace_sizes():
     workspace-size queries answer without a GPU."""
     from diffusionkit_amd import _lib
     lib = _lib.load()
-    for key in (b"gemm", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_balance", b"attn_fuse_q"):
+    for key in (b"gemm", b"gemm_v4", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_fuse_q", b"conv_halo"):
         assert lib.dk_tune_set(key, -1 if key not in (b"gemm_fuse_k", b"attn_fuse_q") else 1) == 0, key
     assert lib.dk_tune_set(b"gemm_sched", 0) == -1  # a knob of the removed kernel generations
     assert b"unknown tuning key" in lib.dk_last_error()
     assert lib.dk_gemm_workspace_bytes() == 256 * 256 * 256 * 4 + 4096
-    assert lib.dk_attention_workspace_bytes() % 1024 == 0 and lib.dk_attention_workspace_bytes() > 4096
+    assert lib.dk_tune_set(b"attn_balance", 1) == -1 and lib.dk_tune_set(b"vae_attn", 0) == -1  # round 5: moved to profiles/lab_kernels
+    assert lib.dk_attention_workspace_bytes() == 0  # (kept for ABI stability: no attention kernel of the library needs a workspace)
     assert lib.dk_attention_set_workspace(None, 0) == 0
 
 

@@ -91,7 +91,8 @@ def test_gemm_segment_mapping_in_place(dev):
     assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP
 
 
-GEMM_MODES = {-1: "automatic choice", 128: "128^2 tiles", 9: "256^2 tiles (16x16x32 MFMA, LDS-DMA ring)"}
+GEMM_MODES = {-1: "automatic choice", 128: "128^2 tiles", 9: "256^2 tiles (16x16x32 MFMA, LDS-DMA ring)",
+              10: "256^2 tiles, one wave per SIMD, hand-scheduled asm body (gemm256v4.hip)"}
 
 
 @pytest.mark.parametrize("mode", sorted(GEMM_MODES))
@@ -173,7 +174,7 @@ def test_gemm_256_joint_stream_in_place(dev):
     o = bf16r(att[:, S_t:] @ w.t() + b)
     ref[:, S_t:] = X[:, S_t:] + bf16r(gate[:, None, h:2 * h] * o)
     ws = ops.gemm_workspace(dev)
-    for mode in (9, -1):
+    for mode in (9, 10, -1):
         Xd, attd, gd = g(X, dev), g(att, dev), g(gate, dev)
         try:
             ops.tune("gemm", mode)
@@ -189,11 +190,11 @@ def test_gemm_256_joint_stream_in_place(dev):
         assert rel_l2(ref[:, S_t:], got[:, S_t:]) < TOL_SINGLE_OP, mode
 
 
-@pytest.mark.parametrize("mf", [8, 7])
+@pytest.mark.parametrize("mf", [8, 7, 104])
 @pytest.mark.parametrize("epi", ["bias", "gate_res", "res"])
 @pytest.mark.parametrize("B,S_t,S_i", [(2, 589, 64), (3, 77, 11), (1, 300, 0)])
 def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi, mf):
-    """The 16x16x32-MFMA 256^2 kernel on the text stream of a joint [B, S_t + S_i] buffer: M = B * S_t is not
+    """(mf 104: the same case on gemm256v4.hip, dk_tune_set("gemm", 10))  The 16x16x32-MFMA 256^2 kernel on the text stream of a joint [B, S_t + S_i] buffer: M = B * S_t is not
     a multiple of 256 and (B > 1) tiles straddle the row segments of every map (A, C, residual, gate), so
     the per-lane row walk of the tail and the clamped DMA rows are exercised; rows of the other stream and
     the rows behind M must stay untouched."""
@@ -218,8 +219,8 @@ def test_gemm_v3_ragged_and_straddling_segments(dev, B, S_t, S_i, epi, mf):
                   gate=gd.data_ptr() + N * 2, gate_seg_len=S_t, gate_stride=2 * N)
         ref[:, :S_t] = X[:, :S_t] + bf16r(gate[:, None, N:] * o)
     try:
-        ops.tune("gemm", 9)
-        ops.tune("gemm_mf", mf)  # 256-row and 224-row tiles
+        ops.tune("gemm", 10 if mf == 104 else 9)
+        ops.tune("gemm_mf", -1 if mf == 104 else mf)  # 256-row and 224-row tiles
         ops.gemm_desc_call(**kw)
     finally:
         ops.tune("gemm", -1)
@@ -247,6 +248,38 @@ def test_gemm_v3_tile_heights_agree(dev, M, N, K):
             ops.tune("gemm_mf", -1)
     assert rel_l2(bf16r(x @ w.t() + b), outs[8].float()) < TOL_SINGLE_OP
     assert torch.equal(outs[8], outs[7]) and torch.equal(outs[8], outs[-1])
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1024, 768, 192), (777, 256, 256), (2048, 1024, 448), (4352, 3072, 3072)])
+def test_gemm_v4_equals_v3(dev, M, N, K, epi):
+    """gemm256v4.hip (one wave per SIMD, asm body: scripts/gen_gemm256v4.py) against gemm256v3.hip: same MFMA, same K order per output
+    element, same staged bf16 image and read-back -- bit-identical outputs.  One to 48 K-tiles (1, 2: the peeled bodies only; 3: one
+    pass of the steady-state loop; 7: odd count), ragged M, every fused epilogue; and against the oracle."""
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=70), randn(N, K, seed=71, scale=0.05), randn(N, seed=72, scale=0.1)
+    res, gate = randn(M, N, seed=73), randn(1, N, seed=74)
+    acc = bf16r(x @ w.t() + b)
+    kw = {}
+    if epi == "gelu":
+        kw, ref = dict(epilogue=ops.DK_EPI_BIAS_GELU), om.gelu_erf(acc, Prec())
+    elif epi == "gate_res":
+        kw, ref = dict(epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev), gate_seg_len=M), res + bf16r(gate * acc)
+    else:
+        ref = acc
+    outs = {}
+    for mode in (9, 10):
+        try:
+            ops.tune("gemm", mode)
+            ops.tune("gemm_mf", 8)
+            ops.tune("gemm_split", 0)
+            outs[mode] = ops.linear(g(x, dev), g(w, dev), g(b, dev), **kw)
+        finally:
+            ops.tune("gemm", -1)
+            ops.tune("gemm_mf", -1)
+            ops.tune("gemm_split", -1)
+    assert rel_l2(ref, outs[10].float()) < TOL_SINGLE_OP
+    assert torch.equal(outs[9], outs[10])
 
 
 # ---- conv ---------------------------------------------------------------------------------------
@@ -391,12 +424,12 @@ def test_attention(dev, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
-@pytest.mark.parametrize("mode", [4, 7, 9])
+@pytest.mark.parametrize("mode", [4, 9])
 @pytest.mark.parametrize("B,H,S,D", [(1, 2, 333, 128), (2, 3, 700, 64), (1, 2, 64, 128), (1, 2, 100, 64), (1, 2, 128, 128), (1, 2, 129, 128), (1, 2, 192, 128), (1, 2, 250, 128), (1, 3, 1088, 128),
                                      (2, 2, 589 + 64, 64), (1, 2, 64, 64), (1, 2, 128, 64), (1, 2, 129, 64), (1, 2, 192, 64), (1, 3, 1088 + 31, 64)])
 def test_attention_kernel_variants(dev, mode, B, H, S, D):
-    """The attention kernels behind dk_tune_set("attn", mode) (4: the VALU-lean kernel with the deferred rescale, 7: the
-    software-pipelined kernel, 9: the phase-alternating kernel, both D = 128; for D = 64 they fall back to the lean kernel) against
+    """The attention kernels behind dk_tune_set("attn", mode) (4: the VALU-lean kernel with the deferred rescale, 9: the
+    phase-alternating kernel, D = 128; for D = 64 it falls back to the lean kernel) against
     the oracle; ragged tail tile, one to 18 key tiles (the phase-alternating kernel's two wave groups stage different tiles)."""
     from diffusionkit_amd import ops
     h = H * D
@@ -410,41 +443,6 @@ def test_attention_kernel_variants(dev, mode, B, H, S, D):
     ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(B, S, h)
     assert rel_l2(ref, y.float()) < 6e-3
     assert max_abs(ref, y.float()) < 0.03
-
-
-@pytest.mark.parametrize("B,H,S,qfuse", [(1, 24, 4352, False),   # FLUX: 408 tasks of 68 tiles on 256 CUs, every workgroup but the last splits a task
-                                         (1, 24, 4352 - 37, False),  # ragged tail tile inside a tail segment
-                                         (2, 17, 3000, False),     # 408 tasks again, two images
-                                         (1, 40, 2048, False)])    # 320 tasks of 32 tiles
-def test_attention_balanced_form(dev, B, H, S, qfuse):
-    """dk_attn3_fwd_kernel<.., BAL = true>: one workgroup per CU over equal ranges of (query block, key tile); a split block's
-    head merges its tail's (m, l, O) from the workspace.  Against the plain grid of the same kernel (same tiles, same order
-    inside a segment; the merge adds one rescale) and against the oracle on a slice; the flags must be left zero."""
-    from diffusionkit_amd import ops
-    D = 128
-    h = H * D
-    qkv = randn(B, S, 3 * h, seed=33)
-    ws = ops.attention_workspace(dev)
-    qd = g(qkv, dev)
-    try:
-        ops.tune("attn", 7)
-        ops.tune("attn_balance", 1)
-        y = ops.attention(qd, H, D, workspace=ws)
-        y2 = ops.attention(qd, H, D, workspace=ws)  # the slots and flags are reusable
-        ops.tune("attn_balance", 0)
-        y0 = ops.attention(qd, H, D, workspace=ws)
-    finally:
-        ops.tune("attn", -1)
-        ops.tune("attn_balance", -1)
-    assert int(ws[-4096:].sum()) == 0
-    assert torch.equal(y, y2)
-    assert max_abs(y0.float(), y.float()) < 0.02
-    assert rel_l2(y0.float(), y.float()) < 2e-3
-    hs = [0, H // 2, H - 1]  # oracle on three heads
-    q, k, v = (torch.stack([qkv[..., i * h + hh * D:i * h + (hh + 1) * D] for hh in hs], 1) for i in range(3))
-    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec())
-    got = torch.stack([y.float().cpu()[..., hh * D:(hh + 1) * D] for hh in hs], 1)
-    assert rel_l2(ref, got) < 6e-3
 
 
 @pytest.mark.parametrize("B,T", [(1, 64), (2, 96), (1, 100), (1, 1000), (2, 4096)])
@@ -485,7 +483,7 @@ def test_attention_spiked_key_forces_rescale(dev):
     p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
     ref = (p @ v[0])[None]
     assert float(p[7, 250]) > 0.9
-    for mode in (4, 7, 9):  # the deferred-rescale kernels (threshold path; 7: pipelined, 9: phase-alternating kernel)
+    for mode in (4, 9):  # the deferred-rescale kernels (threshold path; 9: phase-alternating kernel)
         try:
             ops.tune("attn", mode)
             y = ops.attention(g(qkv, dev), H, D)
