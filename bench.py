@@ -166,7 +166,7 @@ WORKLOAD_NAMES = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-
                   "tiny": "tiny"}
 
 
-def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4):
+def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4, fp8_policy="quality"):
     """One bench leg: build the pipeline of `workload` on this rank, `warmup` untimed images, EXACTLY `steps` timed images
     (each = the denoising steps + the VAE decode) bracketed by barrier + synchronize on both sides, max over ranks; then the
     per-launch HIP-event replay for the roofline figures (rank 0).  Returns a dict of measurements (rank 0) or None."""
@@ -203,7 +203,8 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
         latent, num_steps, cfg_weight, shift, S_t, rows = (16, 16), 4, 0.0, 1.0, 64, 1
     if fp8:
         assert cfg.is_flux and workload != "tiny", "--fp8 is offered for the FLUX workloads (head_dim 128, token counts multiples of 128)"
-        cfg = replace(cfg, weight_dtype="fp8_e4m3")
+        from diffusionkit_amd.config import fp8_config
+        cfg = fp8_config(cfg, fp8_policy)  # "quality": the first 12 double blocks keep bf16 Linears (>= 35 dB per step); "speed": every block fp8
     assert B >= 1 and (B == 1 or rows == 1), "--batch > 1 is offered for the FLUX workloads (one conditioning row per image)"
 
     # ---- weights: rank 0 creates them, one RCCL broadcast of the packed blob over xGMI ----
@@ -434,6 +435,9 @@ def main():
                          "per GPU.  BASELINE configs[4] (FLUX.1-schnell, batch 64 sharded over 8 GPUs) is `--gpus 8 --batch 8`; "
                          "`--batch auto` picks that per-GPU shape (8) whenever --gpus > 1 and 1 on a single GPU")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) weights + MX-fp8 activations on the block-scaled fp8 MFMA (BASELINE configs[3])")
+    ap.add_argument("--fp8-policy", default="quality", choices=["quality", "speed"],
+                    help="quality (default): the first 12 double-stream blocks keep bf16 Linears, >= 35 dB per step against the fp32 oracle; "
+                         "speed: every block Linear in fp8 (32 dB per step)")
     ap.add_argument("--guidance-embed", action="store_true",
                     help="FLUX.1-dev guidance embedding on (config FLUX_DEV); off = the reference's behaviour, which runs dev on the schnell preset")
     ap.add_argument("--overlap-decode", action="store_true",
@@ -476,7 +480,7 @@ def main():
     ctx = {"rank": rank, "world": world, "dev": dev, "lib": lib}
 
     head = run_workload(ctx, args.workload, args.fp8, B, args.steps, args.warmup, guidance_embed=args.guidance_embed,
-                        overlap_decode=args.overlap_decode, want_roofline=not args.no_roofline)
+                        overlap_decode=args.overlap_decode, want_roofline=not args.no_roofline, fp8_policy=args.fp8_policy)
 
     # ---- the other north-star configurations on the same driver-timed line (single-GPU headline runs only): short bounded legs,
     # same code path and timing contract as the headline (warm-up, barrier + synchronize brackets, decode inside the region) ----
@@ -484,9 +488,10 @@ def main():
     if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune:
         other = {}
         for key, (wl, fp8, n_img) in {"sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2),
-                                     "flux-dev-1024 fp8 (BASELINE configs[3])": ("flux-dev-1024", True, 2),
+                                     "flux-dev-1024 fp8 (BASELINE configs[3]; precision policy: first 12 double blocks bf16, >= 35 dB per step)": ("flux-dev-1024", "quality", 2),
+                                     "flux-dev-1024 fp8, every block Linear in fp8 (32 dB per step)": ("flux-dev-1024", "speed", 1),
                                      "sd35-large-1024 (the reference's third model family, mlx/config.py:72-74)": ("sd35-large-1024", False, 1)}.items():
-            r = run_workload(ctx, wl, fp8, 1, n_img, 1, want_roofline=not args.no_roofline, max_replay=1)
+            r = run_workload(ctx, wl, bool(fp8), 1, n_img, 1, want_roofline=not args.no_roofline, max_replay=1, fp8_policy=fp8 or "quality")
             rf = r["roofline"] or {}
             other[key] = {"metric": f"images/sec {WORKLOAD_NAMES[wl]}", "value": r["value"], "unit": "images/s", "steps": n_img, "warmup": 1,
                           "ms_per_step": r["ms_per_step"], "denoise_ms_per_step": r["denoise_ms_per_step"], "vae_decode_ms": r["vae_decode_ms"],

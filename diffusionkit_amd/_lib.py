@@ -65,7 +65,7 @@ class dk_mmdit_config(C.Structure):
         ("pooled_text_embed_dim", C.c_int32), ("token_level_text_embed_dim", C.c_int32),
         ("frequency_embed_dim", C.c_int32), ("max_period", C.c_int32),
         ("embed_dtype", C.c_int32), ("layer_norm_eps", C.c_float),
-        ("guidance_embed", C.c_int32), ("fp8_linears", C.c_int32),
+        ("guidance_embed", C.c_int32), ("fp8_linears", C.c_int32), ("fp8_bf16_double_blocks", C.c_int32),
     ]
 
 
@@ -180,7 +180,7 @@ def load() -> C.CDLL:
             raise DkHipError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dk_abi_version() != 3:
+    if lib.dk_abi_version() != 4:
         raise DkHipError("libdk_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -49,6 +49,9 @@ class MMDiTConfig:
     # storage / MFMA dtype of the transformer blocks' Linear weights: "bfloat16", or "fp8_e4m3" (per-output-channel scales,
     # MX-fp8 activations quantised on the fly; FLUX geometry only: head_dim 128, token counts multiples of 128)
     weight_dtype: str = "bfloat16"
+    # fp8 precision policy (only read with weight_dtype = "fp8_e4m3"): the Linears of the first n double-stream blocks stay bf16 --
+    # an error made in the first blocks travels through all the others (measured dB per block: DESIGN.md section 4)
+    fp8_bf16_double_blocks: int = 0
 
     @property
     def hidden_size(self) -> int:
@@ -115,6 +118,21 @@ FLUX_SCHNELL = MMDiTConfig(
 
 # reference config.py:97-111 (declared there, never selected: quirk Q7)
 FLUX_DEV = replace(FLUX_SCHNELL, guidance_embed=True)
+
+
+# fp8 precision policy of the FLUX family, measured at full depth on MI355X (scripts/fp8_policy_gpu.py, profiles/r05_fp8_policy_gpu.log:
+# Euler direction of teacher-forced steps 1 / 2 / 49 / 50 against the fp32 oracle): every double-stream block kept in bf16 buys ~0.27 dB and
+# costs ~0.36 ms per step; 12 of the 19 put every step at >= 35 dB (35.1 - 36.4 dB, 46.3 ms per step against 41.8 all-fp8 / 61.6 bf16)
+FLUX_FP8_QUALITY_BLOCKS = 12
+
+
+def fp8_config(cfg: MMDiTConfig, policy: str = "quality") -> MMDiTConfig:
+    """``cfg`` on the fp8 path (BASELINE.json configs[3]).  policy "quality" (default): the first FLUX_FP8_QUALITY_BLOCKS double-stream blocks keep
+    bf16 Linears (>= 35 dB per step, SURVEY.md section 8c iii); "speed": every block Linear in fp8 (31.6 - 32.5 dB per step)."""
+    if policy not in ("quality", "speed"):
+        raise ValueError(f"unknown fp8 policy {policy!r} (quality | speed)")
+    n = min(FLUX_FP8_QUALITY_BLOCKS, cfg.depth_multimodal) if policy == "quality" else 0
+    return replace(cfg, weight_dtype="fp8_e4m3", fp8_bf16_double_blocks=n)
 
 
 def tiny_flux(depth_multimodal: int = 2, depth_unified: int = 2, heads: int = 2,

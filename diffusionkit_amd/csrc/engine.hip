@@ -444,6 +444,8 @@ struct dk_mmdit {
   unsigned char *SXN = nullptr, *SATT = nullptr, *SHID = nullptr, *SCAT = nullptr;
   int ldh8 = 0, ldcat8 = 0, nblk = 0;
   bool fp8() const { return cfg.fp8_linears != 0; }
+  // precision policy: the first n_bf16() double-stream blocks keep bf16 Linears under fp8_linears (global block index = double-block index)
+  int n_bf16() const { return fp8() ? (cfg.fp8_bf16_double_blocks < cfg.depth_multimodal ? cfg.fp8_bf16_double_blocks : cfg.depth_multimodal) : 0; }
 
   int h() const { return cfg.hidden_size; }
   int D() const { return cfg.hidden_size / cfg.num_heads; }
@@ -524,8 +526,8 @@ static int need(const std::unordered_map<std::string, const void*>& named, const
 }
 
 // the matrix of one Linear: bf16 "<name>.weight", or (fp8_linears) e4m3 "<name>.weight_fp8" + f32 "<name>.wscale"
-static int need_matrix(dk_mmdit* m, const std::string& name, const bf16_t** w, const unsigned char** w8, const float** ws) {
-  if (!m->fp8()) return need(m->named, name + ".weight", w);
+static int need_matrix(dk_mmdit* m, bool f8, const std::string& name, const bf16_t** w, const unsigned char** w8, const float** ws) {
+  if (!f8) return need(m->named, name + ".weight", w);
   const bf16_t *a = nullptr, *b = nullptr;
   DK_TRY(need(m->named, name + ".weight_fp8", &a));
   DK_TRY(need(m->named, name + ".wscale", &b));
@@ -533,15 +535,15 @@ static int need_matrix(dk_mmdit* m, const std::string& name, const bf16_t** w, c
   *ws = (const float*)b;
   return 0;
 }
-static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool single, bool skip_post) {
+static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool single, bool skip_post, bool f8) {
   const auto& n = m->named;
   if (single) {  // fused [q|k|v|fc1] matrix; fc1 views point into it
-    DK_TRY(need_matrix(m, p + ".linear1", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
+    DK_TRY(need_matrix(m, f8, p + ".linear1", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
     DK_TRY(need(n, p + ".linear1.bias", &w.qkv_b));
-    if (!m->fp8()) w.fc1_w = w.qkv_w + (size_t)3 * m->h() * m->h();
+    if (!f8) w.fc1_w = w.qkv_w + (size_t)3 * m->h() * m->h();
     w.fc1_b = w.qkv_b + 3 * m->h();
   } else {
-    DK_TRY(need_matrix(m, p + ".attn.qkv", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
+    DK_TRY(need_matrix(m, f8, p + ".attn.qkv", &w.qkv_w, &w.qkv_w8, &w.qkv_ws));
     DK_TRY(need(n, p + ".attn.qkv.bias", &w.qkv_b));
   }
   if (m->cfg.use_qk_norm) {
@@ -550,16 +552,16 @@ static int resolve_stream(dk_mmdit* m, const std::string& p, StreamW& w, bool si
   }
   if (skip_post) return 0;
   if (!single) {
-    DK_TRY(need_matrix(m, p + ".mlp.fc1", &w.fc1_w, &w.fc1_w8, &w.fc1_ws));
+    DK_TRY(need_matrix(m, f8, p + ".mlp.fc1", &w.fc1_w, &w.fc1_w8, &w.fc1_ws));
     DK_TRY(need(n, p + ".mlp.fc1.bias", &w.fc1_b));
   }
   if (single) {
-    DK_TRY(need_matrix(m, p + ".linear2", &w.l2_w, &w.l2_w8, &w.l2_ws));
+    DK_TRY(need_matrix(m, f8, p + ".linear2", &w.l2_w, &w.l2_w8, &w.l2_ws));
     DK_TRY(need(n, p + ".linear2.bias", &w.l2_b));
   } else {
-    DK_TRY(need_matrix(m, p + ".attn.o_proj", &w.o_w, &w.o_w8, &w.o_ws));
+    DK_TRY(need_matrix(m, f8, p + ".attn.o_proj", &w.o_w, &w.o_w8, &w.o_ws));
     DK_TRY(need(n, p + ".attn.o_proj.bias", &w.o_b));
-    DK_TRY(need_matrix(m, p + ".mlp.fc2", &w.fc2_w, &w.fc2_w8, &w.fc2_ws));
+    DK_TRY(need_matrix(m, f8, p + ".mlp.fc2", &w.fc2_w, &w.fc2_w8, &w.fc2_ws));
     DK_TRY(need(n, p + ".mlp.fc2.bias", &w.fc2_b));
   }
   return 0;
@@ -596,11 +598,12 @@ static int mmdit_resolve(dk_mmdit* m) {
   m->single.assign(m->cfg.depth_unified, StreamW());
   for (int i = 0; i < m->cfg.depth_multimodal; ++i) {
     const std::string b = "multimodal_transformer_blocks." + std::to_string(i);
-    DK_TRY(resolve_stream(m, b + ".image_transformer_block", m->dimg[i], false, false));
-    DK_TRY(resolve_stream(m, b + ".text_transformer_block", m->dtxt[i], false, m->txt_skipped(i)));
+    const bool f8 = m->fp8() && i >= m->n_bf16();
+    DK_TRY(resolve_stream(m, b + ".image_transformer_block", m->dimg[i], false, false, f8));
+    DK_TRY(resolve_stream(m, b + ".text_transformer_block", m->dtxt[i], false, m->txt_skipped(i), f8));
   }
   for (int i = 0; i < m->cfg.depth_unified; ++i)
-    DK_TRY(resolve_stream(m, "unified_transformer_blocks." + std::to_string(i) + ".transformer_block", m->single[i], true, false));
+    DK_TRY(resolve_stream(m, "unified_transformer_blocks." + std::to_string(i) + ".transformer_block", m->single[i], true, false, m->fp8()));
   m->resolved = true;
   return 0;
 }
@@ -617,7 +620,8 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->ldcat = dk_weight_pitch((1 + m->cfg.mlp_ratio) * h);
   const size_t hid = BS * m->ldh * 2;  // MLP hidden of both streams of a double block (image rows first)
   const size_t cat = m->cfg.depth_unified > 0 ? BS * (size_t)m->ldcat * 2 : 0;
-  m->CAT = (bf16_t*)c.take(m->fp8() ? 0 : (cat > hid ? cat : hid));  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden
+  // single blocks: [attn | gelu(fc1)]; double blocks: MLP hidden (fp8_linears: only the bf16 double blocks of the precision policy need it)
+  m->CAT = (bf16_t*)c.take(m->fp8() ? (m->n_bf16() > 0 ? hid : 0) : (cat > hid ? cat : hid));
   m->HID = m->CAT;
   if (m->fp8()) {  // the same buffers in MX-fp8 (the bf16 X, QKV, ATT above stay: residual stream, attention operands / output)
     const int r = m->cfg.mlp_ratio;
@@ -926,6 +930,17 @@ static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int 
   return 0;
 }
 
+static int mmdit_blocks_fp8(dk_mmdit* m, const bf16_t* mod_step, int first, int count, hipStream_t st);
+static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int count, hipStream_t st);
+// blocks [first, first + count): the bf16 double blocks of the precision policy on the bf16 path, everything else on the model's own
+static int mmdit_blocks(dk_mmdit* m, const bf16_t* mod_step, int first, int count, hipStream_t st) {
+  if (!m->fp8()) return mmdit_blocks_bf16(m, mod_step, first, count, st);
+  const int nb = m->n_bf16(), end = first + count;
+  if (first < nb) DK_TRY(mmdit_blocks_bf16(m, mod_step, first, (end < nb ? end : nb) - first, st));
+  if (end > nb) DK_TRY(mmdit_blocks_fp8(m, mod_step, first > nb ? first : nb, end - (first > nb ? first : nb), st));
+  return 0;
+}
+
 struct MmditCallScope {  // an engine call's GEMM splits go through THAT engine's region; the caller's setting comes back
   LinearWsScope lin;
   explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS) {}
@@ -1068,7 +1083,7 @@ extern "C" int dk_mmdit_forward(dk_mmdit* m, const void* tokens_in, const void* 
   DK_TRY(linear_call((const bf16_t*)tokens_in, F, B * S_i, 0, m->xemb_w, m->xemb_b, m->X + (size_t)S_t * h, h, S_i, S, B * S_i, h, F,
                      c.use_pos_embed ? DK_EPI_RES : DK_EPI_BIAS, nullptr, 0, 0, c.use_pos_embed ? m->POS : nullptr, h, S_i, 0, st));
   const int n_blocks = c.depth_multimodal + c.depth_unified;
-  DK_TRY(m->fp8() ? mmdit_blocks_fp8(m, mod_step, 0, n_blocks, st) : mmdit_blocks_bf16(m, mod_step, 0, n_blocks, st));
+  DK_TRY(mmdit_blocks(m, mod_step, 0, n_blocks, st));
   return mmdit_final_layer(m, mod_step, (bf16_t*)tokens_out, st);
 }
 
@@ -1085,7 +1100,7 @@ extern "C" int dk_mmdit_run_blocks(dk_mmdit* m, const void* x_in, void* x_out, i
   const size_t bytes = (size_t)m->B * m->S * m->h() * 2;
   const bf16_t* mod_step = m->MOD + (size_t)step_index * m->B * m->mod_rows() * m->h();
   DK_CHECK_HIP(hipMemcpyAsync(m->X, x_in, bytes, hipMemcpyDeviceToDevice, st));
-  DK_TRY(m->fp8() ? mmdit_blocks_fp8(m, mod_step, first_block, n_blocks, st) : mmdit_blocks_bf16(m, mod_step, first_block, n_blocks, st));
+  DK_TRY(mmdit_blocks(m, mod_step, first_block, n_blocks, st));
   DK_CHECK_HIP(hipMemcpyAsync(x_out, m->X, bytes, hipMemcpyDeviceToDevice, st));
   return 0;
 }

@@ -259,8 +259,9 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   DK_REQUIRE(p.ldw >= p.K && p.ldw % 8 == 0, "ldw must be >= K and a multiple of 8 elements");
   // the 256^2 kernel (16x16x32 MFMA, LDS-DMA ring, any M and any row-segment map) takes every large-M shape it accepts; small M
   // (modulation tables, embedders, a lone text stream) and N % 256 != 0 stay on the 128^2 tiles
-  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9 || g_dk_gemm_mode == 10);
-  if ((g_dk_gemm_mode == 9 || g_dk_gemm_mode == 10) && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
+  // (mode 10 forces gemm256v4.hip on what IT accepts and leaves every other launch to the automatic choice: usable around a whole model)
+  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9 || (g_dk_gemm_mode == 10 && dk_gemm256v4_eligible(p)));
+  if (g_dk_gemm_mode == 9 && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
   if (big && dk_use_v4(p, nullptr)) return dk_launch_gemm256v4(p, nullptr, stream);
   if (big) return dk_launch_gemm256v3(p, nullptr, stream);
   if (p.kn_w != nullptr) {

@@ -244,8 +244,14 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
     out: Dict[str, Tensor] = {}
     get = (lambda k: w.pop(k)) if consume else (lambda k: w[k])
 
+    n_bf = int(getattr(cfg, "fp8_bf16_double_blocks", 0)) if fp8 else 0
+    keep_bf16 = tuple(f"multimodal_transformer_blocks.{i}." for i in range(min(n_bf, cfg.depth_multimodal)))  # precision policy
+
+    def is_fp8(name):
+        return fp8 and not (keep_bf16 and name.startswith(keep_bf16))
+
     def put(name, t):
-        if fp8 and name.endswith(".weight") and name[:-len(".weight")].endswith(BLOCK_LINEARS):
+        if is_fp8(name) and name.endswith(".weight") and name[:-len(".weight")].endswith(BLOCK_LINEARS):
             base = name[:-len(".weight")]
             q, scale = quantize_weight_e4m3(t.to(device=dev, dtype=bf))  # the bf16 weight is what gets quantised
             k = q.shape[1]
@@ -261,7 +267,7 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
 
     def put_pitched(name, t):
         """Long-reduction weights ([h, 4h] fc2, [h, 5h] linear2): rows at the engine's pitch (dk_weight_pitch, include/dk_hip.h)."""
-        if fp8:
+        if is_fp8(name):
             return put(name, t)  # the fp8 branch of put() applies dk_weight_pitch_fp8
         k = t.shape[1]
         pitch = int(_lib.load().dk_weight_pitch(k))

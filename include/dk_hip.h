@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 3
+#define DK_ABI_VERSION 4
 
 int dk_abi_version(void);
 const char* dk_last_error(void);
@@ -281,6 +281,10 @@ typedef struct dk_mmdit_config {
    * its 4-bit nn.QuantizedLinear checkpoints, model_io.py:728-734,772-775).  Needs head_dim 128 and text / image token
    * counts that are multiples of 128.  0: bf16 weights. */
   int32_t fp8_linears;
+  /* fp8 precision policy (round 5; only read with fp8_linears): the Linears of the first fp8_bf16_double_blocks double-stream blocks
+   * stay bf16 ("<name>.weight", bf16 activations, the bf16 GEMM): errors made in the first blocks travel through all 57 -- measured
+   * dB per step against what the blocks cost in DESIGN.md section 4.  0: every block on the fp8 path. */
+  int32_t fp8_bf16_double_blocks;
 } dk_mmdit_config;
 
 typedef struct dk_mmdit dk_mmdit;

@@ -65,6 +65,7 @@ def fake_quant_block_weights(cfg, named: Dict[str, Tensor]) -> Dict[str, Tensor]
     per row across both parts."""
     out = {k: v.to(torch.float32) for k, v in named.items()}
     bf = torch.bfloat16
+    n_bf = min(int(getattr(cfg, "fp8_bf16_double_blocks", 0)), cfg.depth_multimodal)  # precision policy: these double blocks stay bf16
 
     def rowwise(prefix, names):
         for n in names:
@@ -72,7 +73,7 @@ def fake_quant_block_weights(cfg, named: Dict[str, Tensor]) -> Dict[str, Tensor]
             if key in named:
                 out[key] = fake_quant_weight(named[key].to(bf))
 
-    for i in range(cfg.depth_multimodal):
+    for i in range(n_bf, cfg.depth_multimodal):
         for s in ("image_transformer_block", "text_transformer_block"):
             rowwise(f"multimodal_transformer_blocks.{i}.{s}", ("attn.q_proj", "attn.k_proj", "attn.v_proj", "attn.o_proj", "mlp.fc1", "mlp.fc2"))
     for i in range(cfg.depth_unified):
@@ -82,3 +83,17 @@ def fake_quant_block_weights(cfg, named: Dict[str, Tensor]) -> Dict[str, Tensor]
         both = fake_quant_weight(torch.cat([o, f2], dim=1))
         out[p + ".attn.o_proj.weight"], out[p + ".mlp.fc2.weight"] = both[:, :o.shape[1]], both[:, o.shape[1]:]
     return out
+
+
+def policy_act_quant(cfg):
+    """activation fake-quantiser for OracleMMDiT(act_quant=...) that follows the engine's precision policy: the Linears of the first
+    cfg.fp8_bf16_double_blocks double-stream blocks see un-quantised activations (diffusionkit_amd/config.py: fp8_config)"""
+    n_bf = min(int(getattr(cfg, "fp8_bf16_double_blocks", 0)), cfg.depth_multimodal)
+    keep = tuple(f"multimodal_transformer_blocks.{i}." for i in range(n_bf))
+
+    def aq(x, site=None):
+        if site is not None and keep and site[0].startswith(keep):
+            return x
+        return mx8_fake_quant(x)
+    aq.takes_site = True
+    return aq

@@ -137,7 +137,8 @@ def _fp8_forward_case(cfg, dev, B, Hl, Wl, S_t, ts, step, guidance=None):
     res = {}
     fq = o8.fake_quant_block_weights(cfg, named)
     plain = {k: v.float() for k, v in named.items()}
-    for name, w, P, aq in (("fq_emu", fq, Prec(BF), o8.mx8_fake_quant), ("fq_fp32", fq, Prec(), o8.mx8_fake_quant), ("fp32", plain, Prec(), None)):
+    paq = o8.policy_act_quant(cfg)  # (= mx8_fake_quant on every block Linear unless cfg carries a precision policy)
+    for name, w, P, aq in (("fq_emu", fq, Prec(BF), paq), ("fq_fp32", fq, Prec(), paq), ("fp32", plain, Prec(), None)):
         m = OracleMMDiT(cfg, w, P, act_quant=aq, guidance=guidance)
         m.cache_modulation_params(pooled, torch.tensor(ts))
         taps = {}
@@ -157,6 +158,24 @@ def test_mmdit_fp8_tiny(dev, B):
     print(f"fp8 tiny B={B}: PSNR vs fp32 un-quantised oracle {psnr(res['fp32'], out):.1f} dB (fake-quant oracle: fp32 arithmetic "
           f"{psnr(res['fp32'], res['fq_fp32']):.1f} dB, bf16-emulating {psnr(res['fp32'], res['fq_emu']):.1f} dB)")
     assert psnr(res["fp32"], out) > psnr(res["fp32"], res["fq_emu"]) - 3.0
+
+
+def test_mmdit_fp8_precision_policy_tiny(dev):
+    """MMDiTConfig.fp8_bf16_double_blocks (round 5): the first double-stream block keeps bf16 Linears (bf16 weights, bf16 activations, the
+    bf16 GEMM), the second one and the single blocks run the fp8 path -- against the oracle with exactly those blocks fake-quantised, and
+    closer to the un-quantised oracle than the all-fp8 engine"""
+    base = tiny_flux(depth_multimodal=2, depth_unified=2, heads=2)
+    cfg = replace(base, weight_dtype="fp8_e4m3", fp8_bf16_double_blocks=1)
+    packed = pack_mmdit(cfg, synth_mmdit_weights(cfg, seed=1234), dev)
+    assert "multimodal_transformer_blocks.0.image_transformer_block.attn.qkv.weight" in packed
+    assert "multimodal_transformer_blocks.1.image_transformer_block.attn.qkv.weight_fp8" in packed
+    out, res = _fp8_forward_case(cfg, dev, 1, 32, 32, 128, [1000.0, 752.0, 500.0], 1)
+    e_h, e_e = rel_l2(res["fq_fp32"], out), rel_l2(res["fq_fp32"], res["fq_emu"])
+    assert e_h <= 2.0 * e_e + 2e-3, (e_h, e_e)
+    out_all, _ = _fp8_forward_case(replace(base, weight_dtype="fp8_e4m3"), dev, 1, 32, 32, 128, [1000.0, 752.0, 500.0], 1)
+    p_pol, p_all = psnr(res["fp32"], out), psnr(res["fp32"], out_all)
+    print(f"fp8 tiny, first double block bf16: {p_pol:.1f} dB against the un-quantised oracle, every block fp8: {p_all:.1f} dB")
+    assert p_pol > p_all
 
 
 def test_mmdit_fp8_rejects_unaligned_token_counts(dev):
