@@ -66,6 +66,7 @@ bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 128 == 0, K % 64 == 0, 
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 // gemm256v4.hip: one wave per SIMD, 256 accumulators in AGPRs, hand-scheduled asm body (N % 256 == 0, no conv / K split / half tiles)
 extern int g_dk_v4_auto;  // gemm.hip
+extern int g_dk_v4_skew;  // gemm256v4.hip
 bool dk_gemm256v4_eligible(const GemmParams& p);
 int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream);  // gemm256v3.hip (16x16x32 MFMA K loop)

@@ -38,6 +38,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   DK_REQUIRE(key != nullptr, "null key");
   if (strcmp(key, "gemm") == 0) { g_dk_gemm_mode = value; return 0; }
   if (strcmp(key, "gemm_v4") == 0) { g_dk_v4_auto = value; return 0; }
+  if (strcmp(key, "gemm_skew") == 0) { g_dk_v4_skew = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
   if (strcmp(key, "gemm_fuse_k") == 0) { g_dk_fuse_k = value; return 0; }

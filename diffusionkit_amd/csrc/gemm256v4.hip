@@ -228,9 +228,16 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b) {
+__global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, int skew) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(v4_lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
+  // Start skew (multi-round launches): the first round's workgroups start up to `skew` x 0.25 us apart (by their position inside their
+  // XCD), and every later round inherits the spread -- without it all 256 CUs reach their tails at the same moment and 256 x 128 KiB of
+  // C leave in one burst per round while the matrix pipes idle (profiles/r03_gemm_k_sweep_ablations.log: 2.4 us of a 9.8 us fixed cost)
+  if (skew > 0 && blockIdx.x < 256) {
+    const int n = (int)((blockIdx.x >> 3) & 31) * skew / 32;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,6 +352,8 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   }
 }
 
+int g_dk_v4_skew = -1;  // dk_tune_set("gemm_skew", v): start skew of multi-round launches in 0.25 us steps; -1 (default): 32 when the last round is partial
+
 // dk_tune_set("gemm", 10) forces this kernel on every shape it accepts; -1 (automatic): see dk_launch_gemm / dk_launch_gemm_pair
 bool dk_gemm256v4_eligible(const GemmParams& p) {
   if (p.conv || !dk_gemm256v3_eligible(p)) return false;
@@ -371,7 +380,12 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
-  hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b);
+  // start skew: only where there is a second round to inherit it, and (automatic choice) only when the last round is a partial one -- the CUs
+  // that start first take its tiles, so the spread costs nothing there (profiles/r05_gemm_v4_start_skew.log: linear1 -1.4 %, the 2.25-round
+  // q / k / v shapes -3 ... -4 %); with a whole number of rounds the launch simply ends `skew` later (+0 ... +1 %)
+  const int tiles = tiles_a + tiles_b, frac = tiles % 256;
+  const int skew = tiles <= 256 ? 0 : g_dk_v4_skew >= 0 ? g_dk_v4_skew : (frac > 0 && frac <= 224 ? 32 : 0);
+  hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -159,7 +159,7 @@ def test_tune_keys_and_workspace_sizes():
     workspace-size queries answer without a GPU."""
     from diffusionkit_amd import _lib
     lib = _lib.load()
-    for key in (b"gemm", b"gemm_v4", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_fuse_q", b"conv_halo"):
+    for key in (b"gemm", b"gemm_v4", b"gemm_skew", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_fuse_q", b"conv_halo"):
         assert lib.dk_tune_set(key, -1 if key not in (b"gemm_fuse_k", b"attn_fuse_q") else 1) == 0, key
     assert lib.dk_tune_set(b"gemm_sched", 0) == -1  # a knob of the removed kernel generations
     assert b"unknown tuning key" in lib.dk_last_error()

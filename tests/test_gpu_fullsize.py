@@ -98,7 +98,7 @@ def start_synth_prefetch():
     if _SYNTH_THREAD:
         return
     small = []
-    for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 2)):
+    for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 3)):
         small.append((_synth_key(c["cfg"], c["seed_w"]), c["cfg"], c["seed_w"], uses))
     big = [(_synth_key(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"]), fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], 1)]
     _SYNTH_PLAN.extend(big + small)
@@ -388,6 +388,84 @@ def test_sd3_medium_1024_full_depth_cfg_late_steps(dev):
     packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True)}
     pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
     check_forced("sd3_full_late", f, forced_steps(pipe, c, dev), "sd3_full_late")
+
+
+# ---- round 5: closed-loop trajectories of the 50-step configurations (VERDICT r4 "Next round" item 2) ---------------------------------
+CLOSED_TOL = {
+    # case: (min PSNR dB, max rel-L2) of the FINAL latent against the fp32 oracle's, every gate = measured - 2 dB / x 1.5
+    # (profiles/r05_fullsize_parity.log); the intermediate latents are printed (how the distance grows along the trajectory)
+    "sd3_full_50": (0.0, 1e9),
+    "sd3_full_50_image": (0.0, None),
+    "flux_dev_10": (0.0, 1e9),
+    "flux_dev_10_fp8": (0.0, 1e9),
+    "flux_dev_10_fp8_policy": (0.0, 1e9),
+}
+
+
+def check_closed(name, ref, got, key):
+    p, e = psnr(ref, got), rel_l2(ref, got)
+    print(f"[fullsize] {name}: final latent PSNR {p:.2f} dB, rel-L2 {e:.4e}, max-abs {float((ref.double() - got.double()).abs().max()):.4g}")
+    min_p, max_e = CLOSED_TOL[key]
+    assert p >= min_p, f"{name}: PSNR {p:.2f} dB < {min_p}"
+    assert max_e is None or e <= max_e, f"{name}: rel-L2 {e:.3e} > {max_e}"
+
+
+def test_sd3_medium_1024_closed_loop_50_steps(dev):
+    """BASELINE configs[2] END TO END, closed loop: SD3-medium, 24 blocks, CFG 5.0 (B = 2), 589 text tokens, latent 128 x 128, all 50 Euler
+    steps of the 50-step schedule through the pipeline's own sample_euler / CFGDenoiser (mlx/__init__.py:761-788), every step from the
+    latent the previous one left -- the latent after steps 1 / 3 / 10 / 20 / 30 / 40 / 50 against the fp32 oracle's trajectory, and the
+    decoded 1024 x 1024 image (uint8, the reference's image PSNR metric utils.py:52-67) against the oracle's decode of ITS final latent"""
+    from diffusionkit_amd.pipeline import CFGDenoiser, DiffusionPipeline, sample_euler
+    from oracle.pipeline import image_psnr
+    f = load("sd3_full_50")
+    c = fx.SD3_FULL_50
+    packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True),
+              "vae_decoder": pack_vae(VAEDecoderConfig(), synth_vae_weights(VAEDecoderConfig(), seed=c["seed_vae"]), dev)}
+    pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
+    text, pooled = fx.sd3_full_inputs()
+    sig = pipe.get_sigmas(pipe.sampler, c["steps_of"])
+    x0_ref, sig_ref = fx.sd3_full_start(c)
+    assert np.allclose(np.asarray(sig, dtype=np.float64), sig_ref.numpy().astype(np.float64), rtol=0, atol=1e-7)
+    extra = {"conditioning": text.to(dev, BF), "cfg_weight": c["cfg_weight"], "pooled_conditioning": pooled.to(dev, BF)}
+    x = x0_ref.to(dev)
+    prev = 0
+    for k in c["keep"]:  # the loop in pieces: same modulation table rows (step indices of the full schedule), same arithmetic
+        x, _ = sample_euler(CFGDenoiser(pipe), x, sig[prev: k + 1], extra_args=dict(extra))  # (timesteps = the schedule's own entries)
+        prev = k
+        ref = torch.from_numpy(f["x_step50_fp32"] if k == 50 else f[f"x_step{k}_f16"].astype(np.float32))
+        got = x.float().cpu()
+        print(f"[fullsize] sd3_full_50 after step {k:2d}: PSNR {psnr(ref, got):.2f} dB, rel-L2 {rel_l2(ref, got):.3e} (latent rms {float(ref.pow(2).mean().sqrt()):.3f})")
+    check_closed("sd3_full_50", torch.from_numpy(f["x_step50_fp32"]), x.float().cpu(), "sd3_full_50")
+    img, u8, _ = pipe.decoder.decode(pipe.latent_format.process_out(x))
+    p_img = image_psnr(f["image_u8"], u8[0].cpu().numpy())
+    print(f"[fullsize] sd3_full_50 decoded image (uint8, the reference's image_psnr): {p_img:.2f} dB")
+    assert p_img >= CLOSED_TOL["sd3_full_50_image"][0]
+
+
+def _flux_dev_10(dev, fp8, key):
+    f = load("flux_dev_10")
+    c = fx.FLUX_DEV_10
+    pipe = flux_full_pipe(dev, fp8=fp8)
+    text, pooled = fx.flux_dev_10_inputs()
+    lat, it = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"], seed=c["noise_seed"])
+    assert len(it) == c["steps"]
+    check_closed(f"flux_dev_10 ({key})", torch.from_numpy(f["latent_fp32"]), lat.float().cpu(), key)
+
+
+def test_flux_dev_shape_closed_loop_10_steps(dev):
+    """BASELINE configs[3]'s shape closed loop: 19 + 38 blocks, S_t = 512, a COMPLETE 10-step schedule (sigma 1 -> 0) through denoise_latents,
+    bf16 weights -- final latent against the fp32 oracle's"""
+    _flux_dev_10(dev, False, "flux_dev_10")
+
+
+def test_flux_dev_shape_closed_loop_10_steps_fp8(dev):
+    """... every block Linear in fp8 (e4m3 weights, MX-fp8 activations): what ten 32 dB steps do to the image"""
+    _flux_dev_10(dev, True, "flux_dev_10_fp8")
+
+
+def test_flux_dev_shape_closed_loop_10_steps_fp8_policy(dev):
+    """... and the shipped precision policy (first 12 double-stream blocks bf16)"""
+    _flux_dev_10(dev, "quality", "flux_dev_10_fp8_policy")
 
 
 def test_eight_seeds_one_step_loop_equal_single_runs(dev):
