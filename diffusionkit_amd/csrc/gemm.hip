@@ -243,9 +243,12 @@ static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   if (g_dk_gemm_mode != 10 && (g_dk_gemm_mode != -1 || g_dk_v4_auto == 0)) return false;
   if (!dk_gemm256v4_eligible(a) || (b != nullptr && !dk_gemm256v4_eligible(*b))) return false;
   if (g_dk_gemm_mode == 10) return true;
-  // short reductions stay on gemm256v3.hip: this kernel's fixed cost per tile is ~1 us higher (a lone wave drains and writes out the whole
-  // 128 x 128 block), a third of a K = 1536 tile's time -- SD3-medium in the model: 21.2 against 20.3 ms per step (profiles/r05_gemm_v4_in_model.log)
-  if (a.K < 2048) return false;
+  // short reductions: this kernel's fixed cost per tile is ~ 1 us higher (a lone wave drains and writes out the whole 128 x 128 block), a third
+  // of a K = 1536 tile's time, and its per-row tail path (ragged M: SD3's 2 x 589 text rows) is slower still -- SD3-medium in the model:
+  // every eligible launch 22.0 against 21.5 ms per step, launches of whole 256-row tiles only (the image stream's fc1) 21.2
+  // (profiles/r05_gemm_v4_in_model.log).  ("gemm_v4" 2: lab, no such restriction)
+  const bool ragged = a.M % 256 != 0 || (b != nullptr && b->M % 256 != 0);
+  if (a.K < 2048 && ragged && g_dk_v4_auto != 2) return false;
   long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
   if (b) tiles += (long)((b->M + 255) / 256) * (b->N / 256);
   const long frac = tiles % 256;

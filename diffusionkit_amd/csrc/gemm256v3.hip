@@ -205,10 +205,31 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
         const int y = rem / p.cW, x = rem - y * p.cW;
         la[hh][j] = ((unsigned)b << 24) | ((unsigned)y << 12) | (unsigned)x;
       } else {
-        const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
-        la[hh][j] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
+        la[hh][j] = (unsigned)m;  // (mapped through the row segments below)
       }
     }
+  }
+  if (!CONV) {
+    // a tile inside one row segment (every tile of an image stream) maps its rows with one scalar division instead of four per lane
+    // (round 5: the per-lane integer divisions were ~ 0.3 us in front of the first DMA piece of every tile)
+    const int a_seg0 = m0 / p.a_seg_len;
+    const bool a_uniform = min(m0 + BM - 1, p.M - 1) / p.a_seg_len == a_seg0;
+    const int a_base = a_seg0 * p.a_seg_stride - a_seg0 * p.a_seg_len;
+    if (a_uniform) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) la[hh][j] += (unsigned)a_base;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) la[hh][j] = (unsigned)(((int)la[hh][j] / p.a_seg_len) * p.a_seg_stride + ((int)la[hh][j] % p.a_seg_len));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) la[hh][j] = (la[hh][j] * (unsigned)p.lda + (lch[j] >> 1)) * 2u;
   }
   // CONV: tap (dy, dx in -1..1) and channel byte offset of the NEXT activation K-tile to be issued; stored tensor [cB, Hs, Ws, cC]
   const int cv_ush = CONV && p.ups == 1 ? 1 : 0;

@@ -266,15 +266,31 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   // 16-byte chunk (lane & 7) of LDS row r holds global chunk (lane & 7) ^ ((r >> 1) & 7) (conflict-free ds_read_b128, gemm256v3.hip)
   const int srow = lane >> 3;
   u32x8 voX, voW;
+  // (a tile that lies inside one row segment -- every tile of the image stream -- maps its rows with one scalar division instead of eight
+  //  per lane: the integer divisions were ~ 0.4 us in front of the first DMA piece of every tile)
+  const int a_seg0 = m0 / p.a_seg_len;
+  const bool a_uniform = min(m0 + V4_T - 1, p.M - 1) / p.a_seg_len == a_seg0;
+  const int a_base = a_seg0 * p.a_seg_stride - a_seg0 * p.a_seg_len;
 #pragma unroll
   for (int gg = 0; gg < 8; ++gg) {
     const int hh = gg & 1, j = (gg >> 1) & 1, u = gg >> 2;
     const int row = hh * 128 + (wave * 2 + u) * 16 + j * 8 + srow;
     const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);
-    const int m = min(m0 + row, p.M - 1);  // rows beyond M - 1 re-read the last row, their results are never stored
-    const unsigned phys = (unsigned)((m / p.a_seg_len) * p.a_seg_stride + (m % p.a_seg_len));
-    voX[gg] = (phys * (unsigned)p.lda + chunk * 8) * 2u;
+    voX[gg] = (unsigned)min(m0 + row, p.M - 1);  // rows beyond M - 1 re-read the last row, their results are never stored
     voW[gg] = ((unsigned)row * (unsigned)p.ldw + chunk * 8) * 2u;
+  }
+  if (a_uniform) {  // (a scalar branch: the divisions below are not executed)
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) voX[gg] += (unsigned)a_base;
+  } else {
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) voX[gg] = (unsigned)(((int)voX[gg] / p.a_seg_len) * p.a_seg_stride + ((int)voX[gg] % p.a_seg_len));
+  }
+#pragma unroll
+  for (int gg = 0; gg < 8; ++gg) {
+    const int j = (gg >> 1) & 1;
+    const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);
+    voX[gg] = (voX[gg] * (unsigned)p.lda + chunk * 8) * 2u;
   }
   // fragment read addresses (X kk0, X kk1, W kk0, W kk1) and the two drain addresses
   u32x4 rd;
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   }
 }
 
-int g_dk_v4_skew = -1;  // dk_tune_set("gemm_skew", v): start skew of multi-round launches in 0.25 us steps; -1 (default): 32 when the last round is partial
+int g_dk_v4_skew = -1;  // dk_tune_set("gemm_skew", v): start skew of multi-round launches in 0.25 us steps; -1 (default): none
 
 // dk_tune_set("gemm", 10) forces this kernel on every shape it accepts; -1 (automatic): see dk_launch_gemm / dk_launch_gemm_pair
 bool dk_gemm256v4_eligible(const GemmParams& p) {
@@ -384,7 +400,10 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   // that start first take its tiles, so the spread costs nothing there (profiles/r05_gemm_v4_start_skew.log: linear1 -1.4 %, the 2.25-round
   // q / k / v shapes -3 ... -4 %); with a whole number of rounds the launch simply ends `skew` later (+0 ... +1 %)
   const int tiles = tiles_a + tiles_b, frac = tiles % 256;
-  const int skew = tiles <= 256 ? 0 : g_dk_v4_skew >= 0 ? g_dk_v4_skew : (frac > 0 && frac <= 224 ? 32 : 0);
+  // ... in the lab with warm weights.  Inside the model (weights from HBM) the same A/B is flat: 58.78 / 58.81 against 58.86 / 58.94 ms per FLUX
+  // step (profiles/r05_gemm_v4_start_skew.log) -- the automatic choice keeps it off; dk_tune_set("gemm_skew", n) turns it on
+  (void)frac;
+  const int skew = tiles <= 256 || g_dk_v4_skew < 0 ? 0 : g_dk_v4_skew;
   hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());

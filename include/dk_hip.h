@@ -388,7 +388,7 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
 /* Tuning knobs for A/B measurements (no reference counterpart); -1 = automatic (the shipped default) for every key.
  * "gemm": 128 = 128x128 tiles only, 9 = the 8-wave 256x256 kernel on every shape it accepts, 10 = the one-wave-per-SIMD 256x256 kernel
  * (asm body) on every shape IT accepts; "gemm_v4": 0 = the automatic choice never takes the latter; "gemm_skew": start skew of that kernel's
- * multi-round launches in 0.25 us steps (-1: 32 when the last round of the CUs is a partial one); "gemm_mf": 8 / 7 = 256- / 224-row
+ * multi-round launches in 0.25 us steps (-1: none); "gemm_mf": 8 / 7 = 256- / 224-row
  * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
  * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise); "attn_fuse_q": 0 = stand-alone query

@@ -36,16 +36,21 @@ def main():
     print("| kernel | launches | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM bytes/launch (2*fetch + write) |\n|---|---|---|---|---|")
     for k, n, f, w, b in rows[:14]:
         print(f"| `{k[:70]}` | {n} | {f:.0f} | {w:.0f} | {b:.4g} |")
-    # the dominant GEMM kernel of the run = the GEMM kernel with the most bytes over all its launches (rows are sorted that way)
-    dom = [r for r in rows if "gemm256" in r[0]] or [r for r in rows if "gemm" in r[0]]
+    # the block Linears' GEMM kernels of the run (bench.py's roofline class 0: gemm256v4 + gemm256v3 instantiations), launch-weighted
+    dom = [r for r in rows if "gemm256v" in r[0]] or [r for r in rows if "gemm" in r[0]]
     if dom:
-        k, n, f, w, b = dom[0]
-        out = {"kernel": k, "launches": n, "fetch_kib_per_launch_raw": f, "write_kib_per_launch": w, "hbm_bytes_per_launch": b,
+        n_all = sum(r[1] for r in dom)
+        f = sum(r[2] * r[1] for r in dom) / n_all
+        w = sum(r[3] * r[1] for r in dom) / n_all
+        b = sum(r[4] * r[1] for r in dom) / n_all
+        out = {"kernel": " + ".join(f"{r[0].split('(')[0].replace('void ', '')} ({r[1]} launches)" for r in dom) + ", launch-weighted",
+               "launches": n_all, "fetch_kib_per_launch_raw": f, "write_kib_per_launch": w, "hbm_bytes_per_launch": b,
+               "per_instantiation": {r[0].split("(")[0].replace("void ", ""): {"launches": r[1], "hbm_bytes_per_launch": r[4]} for r in dom},
                "correction": "FETCH_SIZE doubled (gfx950 wide-read under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
                "source": root}
         dst = os.path.join(root, "pmc_gemm_traffic.json")  # copy to profiles/pmc_gemm_traffic.json (only gpurun_out/ travels back)
         json.dump(out, open(dst, "w"), indent=1)
-        print("\nwrote", dst, json.dumps(out)[:300])
+        print("\nwrote", dst, json.dumps(out)[:400])
 
 
 if __name__ == "__main__":

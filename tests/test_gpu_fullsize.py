@@ -394,8 +394,8 @@ def test_sd3_medium_1024_full_depth_cfg_late_steps(dev):
 CLOSED_TOL = {
     # case: (min PSNR dB, max rel-L2) of the FINAL latent against the fp32 oracle's, every gate = measured - 2 dB / x 1.5
     # (profiles/r05_fullsize_parity.log); the intermediate latents are printed (how the distance grows along the trajectory)
-    "sd3_full_50": (0.0, 1e9),
-    "sd3_full_50_image": (0.0, None),
+    "sd3_full_50": (49.5, 1.53e-2),     # measured 51.52 dB / 1.018e-2 after 50 steps (78.6 dB after step 1, 65.3 after 10, 56.5 after 30: rel-L2 grows ~ linearly)
+    "sd3_full_50_image": (44.4, None),  # measured 46.41 dB with the reference's own image metric (its gate for a trained model: 20 dB, tests/mlx/test_diffusion_pipeline.py:20)
     "flux_dev_10": (0.0, 1e9),
     "flux_dev_10_fp8": (0.0, 1e9),
     "flux_dev_10_fp8_policy": (0.0, 1e9),
@@ -425,7 +425,8 @@ def test_sd3_medium_1024_closed_loop_50_steps(dev):
     text, pooled = fx.sd3_full_inputs()
     sig = pipe.get_sigmas(pipe.sampler, c["steps_of"])
     x0_ref, sig_ref = fx.sd3_full_start(c)
-    assert np.allclose(np.asarray(sig, dtype=np.float64), sig_ref.numpy().astype(np.float64), rtol=0, atol=1e-7)
+    # (the pipeline's and the oracle's schedules agree to 1.1e-7: the two evaluate sampler.py:31-35 in different orders of fp32 operations)
+    assert np.allclose(np.asarray(sig, dtype=np.float64), sig_ref.numpy().astype(np.float64), rtol=0, atol=2e-7)
     extra = {"conditioning": text.to(dev, BF), "cfg_weight": c["cfg_weight"], "pooled_conditioning": pooled.to(dev, BF)}
     x = x0_ref.to(dev)
     prev = 0
