@@ -602,6 +602,9 @@ static int mmdit_resolve(dk_mmdit* m) {
     const bool f8 = m->fp8() && i >= m->n_bf16();
     DK_TRY(resolve_stream(m, b + ".image_transformer_block", m->dimg[i], false, false, f8));
     DK_TRY(resolve_stream(m, b + ".text_transformer_block", m->dtxt[i], false, m->txt_skipped(i), f8));
+    // (the fused QKNorm decisions of a double block are taken per stream from these pointers and must agree: ADVICE r4)
+    DK_REQUIRE((m->dimg[i].qn == nullptr) == (m->dtxt[i].qn == nullptr) && (m->dimg[i].kn == nullptr) == (m->dtxt[i].kn == nullptr),
+               "QKNorm weights must be bound for both streams of a double block or for neither");
   }
   for (int i = 0; i < m->cfg.depth_unified; ++i)
     DK_TRY(resolve_stream(m, "unified_transformer_blocks." + std::to_string(i) + ".transformer_block", m->single[i], true, false, m->fp8()));

@@ -263,7 +263,11 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   // the 256^2 kernel (16x16x32 MFMA, LDS-DMA ring, any M and any row-segment map) takes every large-M shape it accepts; small M
   // (modulation tables, embedders, a lone text stream) and N % 256 != 0 stay on the 128^2 tiles
   // (mode 10 forces gemm256v4.hip on what IT accepts and leaves every other launch to the automatic choice: usable around a whole model)
-  const bool big = !p.conv && g_dk_gemm_mode != 128 && dk_gemm256v3_eligible(p) && (p.M >= 1024 || g_dk_gemm_mode == 9 || (g_dk_gemm_mode == 10 && dk_gemm256v4_eligible(p)));
+  // (N % 256 == 128 -- the half column tile -- only where the wasted half tile is a small fraction: SD3.5-large's N = 2432 / 7296; a small
+  //  N such as the VAE's 128-channel shortcut Linear stays on the 128^2 tiles: ADVICE r4)
+  const bool half_ok = p.N % 256 == 0 || p.N >= 1024 || g_dk_gemm_mode == 9;
+  const bool big = !p.conv && g_dk_gemm_mode != 128 && half_ok && dk_gemm256v3_eligible(p) &&
+                   (p.M >= 1024 || g_dk_gemm_mode == 9 || (g_dk_gemm_mode == 10 && dk_gemm256v4_eligible(p)));
   if (g_dk_gemm_mode == 9 && !p.conv) DK_REQUIRE(big, "gemm256v3 forced but the shape does not allow it");
   if (big && dk_use_v4(p, nullptr)) return dk_launch_gemm256v4(p, nullptr, stream);
   if (big) return dk_launch_gemm256v3(p, nullptr, stream);
@@ -332,7 +336,8 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
   if (a.ldw <= 0) a.ldw = a.K;
   if (b.ldw <= 0) b.ldw = b.K;
   const bool same = a.N == b.N && a.K == b.K && a.epi == b.epi && a.alpha == b.alpha && a.n_split == 0 && b.n_split == 0;
-  if ((g_dk_gemm_mode == -1 || g_dk_gemm_mode == 10) && same && (a.M >= 1024 || b.M >= 1024) && dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
+  if ((g_dk_gemm_mode == -1 || g_dk_gemm_mode == 10) && same && (a.M >= 1024 || b.M >= 1024) && (a.N % 256 == 0 || a.N >= 1024) &&
+      dk_gemm256v3_eligible(a) && dk_gemm256v3_eligible(b)) {
     // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial extra wave costs more
     // than the small separate launch) ...
     const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);

@@ -329,6 +329,17 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   const int nk = p.K / V4_BK;
   const float alpha = p.alpha;
 
+#ifdef V4_TRACE  // lab (scripts/build_lab.sh TRACE=1): time stamps of workgroups 0 and gridDim.x - 1, wave 0, into p.workspace
+  unsigned long long t_entry = __builtin_readcyclecounter(), ts0, ts1, ts2, ts3;
+  asm volatile(
+#include "../../profiles/lab_kernels/gemm256v4_variants/gemm256v4_asm_trace.inc"
+      : "={s[74:75]}"(ts0), "={s[76:77]}"(ts1), "={s[78:79]}"(ts2), "={s[80:81]}"(ts3)
+      : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), [wave] "s"(wave), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd),
+        "{v[24:25]}"(dr), "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
+      :
+#include "gemm256v4_clobbers.inc"
+  );
+#else
   asm volatile(
 #include "gemm256v4_asm.inc"
       :
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
       :
 #include "gemm256v4_clobbers.inc"
   );
+#endif
 
   // ---------------- tail: staged bf16 image -> row-major, epilogues on the way ----------------
   const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
@@ -366,6 +378,13 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   } else {
     v4_rows<false, -1, false>(t);
   }
+#ifdef V4_TRACE
+  if (p.workspace != nullptr && wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's stores have left)
+    unsigned long long* o = (unsigned long long*)p.workspace + (blockIdx.x == 0 ? 0 : 8);
+    o[0] = t_entry; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 int g_dk_v4_skew = -1;  // dk_tune_set("gemm_skew", v): start skew of multi-round launches in 0.25 us steps; -1 (default): none

@@ -173,6 +173,24 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms / iters < best[v]) best[v] = ms / iters;
       }
+    if (getenv("LAB_TRACE")) {  // a -DV4_TRACE build of gemm256v4.hip (scripts/build_lab.sh TRACE=1): s_memtime stamps of workgroups 0 and last, wave 0
+      dk_tune_set("gemm", 10);
+      d.C = C[0];
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(ws, 0, 256));
+        dk_gemm_bf16(&d, st);
+        CK(hipStreamSynchronize(st));
+        unsigned long long t[16];
+        CK(hipMemcpy(t, ws, sizeof(t), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 2; ++b) {
+          const unsigned long long* o = t + 8 * b;
+          if (o[5] == 0) continue;
+          printf("  trace %-22s %s workgroup (shader cycles): entry -> first DMA %5llu | -> first K-tile landed %6llu | K loop %8llu | drain %6llu | tail (incl. vmcnt(0) of its stores) %6llu | total %8llu\n",
+                 s.name, b == 0 ? "first" : "last ", o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[5] - o[4], o[5] - o[0]);
+        }
+      }
+      CK(hipMemset(ws, 0, 256));
+    }
     const double fl = 2.0 * s.M * s.N * s.K;
     printf("%-26s %5dx%5dx%5d ", s.name, s.M, s.N, s.K);
     for (int v = 0; v < NV; ++v) printf(" m%d: %7.1f TF", modes[v], fl / best[v] / 1e9);

@@ -180,8 +180,13 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4):
     return out
 
 
-def program(nbar=4, stagger=False):
+def program(nbar=4, stagger=False, trace=False):
+    """trace (lab): s_memtime stamps in s[74:75] (first DMA piece issued), s[76:77] (first K-tile landed, barrier passed), s[78:79] (K loop
+    done), s[80:81] (drain done) -- read back by the -DV4_TRACE build of gemm256v4.hip"""
     P = []
+
+    def stamp(lo):
+        return [I("nop", f"s_memtime s[{lo}:{lo + 1}]")] if trace else []
     # ---- inputs -> working registers
     for d, s in ((RX[0], 16), (RX[1], 17), (RW[0], 18), (RW[1], 19)):
         P.append(I("v_mov", f"v_mov_b32 v{d}, v{s}", dst=d, src=s))
@@ -201,6 +206,7 @@ def program(nbar=4, stagger=False):
                 I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000),
                 I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000)]
     # ---- prologue: K-tile 0 into slot 0, K-tile 1 (if any) into slot 1; the accumulators are zeroed while the pieces fly
+    P.extend(stamp(74))
     for g in range(8):
         P.extend(pro_dma("X", g))
     for g in range(8):
@@ -223,6 +229,7 @@ def program(nbar=4, stagger=False):
     P.append(wait(vm=0))
     P.append(I("label", "11:", name="L11"))
     P.append(BARRIER())
+    P.extend(stamp(76))
     # first slice of K-tile 0 (slot 0: the address registers point there); the kk1 registers are toggled at the head of every body,
     # so they start on slot 1
     P.append(I("v_xor", f"v_xor_b32 v{RX[1]}, 0x8000, v{RX[1]}", dst=RX[1], imm=0x8000))
@@ -259,6 +266,7 @@ def program(nbar=4, stagger=False):
         if w is not None and w != copies[-1]:
             P.append(I("branch", "s_branch 90f", target="DRAIN"))
     P.append(I("label", "90:", name="DRAIN"))
+    P.extend(stamp(78))
     # ---- drain: bf16(alpha * acc + bias) into the staging image (every wave is past the last body's release barrier(s): ring free)
     P.append(BARRIER())
     t = 32  # temporaries v[32:..] (the fragment registers are dead)
@@ -279,6 +287,9 @@ def program(nbar=4, stagger=False):
             off = vwn * 16384 + ni * 8192 + mfi * 1024
             P.append(I("ds_write", f"ds_write_b64 v{24 + nf}, v[{r}:{r + 1}] offset:{off}", addr=24 + nf, src=r, off=off))
     P.append(wait(lgkm=0))
+    P.extend(stamp(80))
+    if trace:
+        P.append(wait(lgkm=0))
     return P
 
 
@@ -305,6 +316,11 @@ def emit(path, lab_dir=None):
             f.write(f"// variant {v}: {nbar} barriers per K-tile, {'one loop copy per wave with its own DMA slots' if stagger else 'one loop for all waves'}; "
                     f"{len(P)} instructions, {n_mfma} MFMAs; explicit registers: see the script's header.\n")
             f.write("\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n")
+    if lab_dir is not None:  # the shipped schedule with s_memtime stamps (lab builds with -DV4_TRACE)
+        Pt = program(*VARIANTS[0], trace=True)
+        with open(os.path.join(lab_dir, "gemm256v4_asm_trace.inc"), "w") as f:
+            f.write("// GENERATED by scripts/gen_gemm256v4.py --lab: variant 0 with s_memtime stamps in s[74:81]\n")
+            f.write("\n".join('    "' + ins.text + '\\n"' for ins in Pt) + "\n")
     with open(path.replace("_asm.inc", "_clobbers.inc"), "w") as f:
         f.write("// GENERATED by scripts/gen_gemm256v4.py\n")
         f.write(", ".join('"' + c + '"' for c in CLOBBERS) + "\n")

@@ -23,7 +23,9 @@ from tests._util import BF, TOL_SINGLE_OP, bf16r, psnr, randn, rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,h", [(256, 256), (300, 3072), (4352, 3072), (128, 12288 // 8)])
+# (2560, 384, 2432: h / 8 is not a multiple of 64 -- the last of a lane's 16-byte chunks lies past the row end for some lanes and relies on the
+#  per-row buffer resource: zeros in, stores dropped)
+@pytest.mark.parametrize("M,h", [(256, 256), (300, 3072), (4352, 3072), (128, 12288 // 8), (200, 2560), (130, 384), (64, 2432)])
 def test_quantize_mx8_bit_exact(dev, M, h):
     x = randn(M, h, seed=M + h, scale=2.0)
     x[3, 5:40] = 0.0
@@ -49,9 +51,10 @@ def test_quantize_mx8_into_wider_buffer(dev):
     assert torch.equal(f8.array_to_scales(sc, M, h, rows=rows, row0=128, col0=512), e_ref)
 
 
-def test_ln_modulate_mx8(dev):
+@pytest.mark.parametrize("h", [1024, 2560, 384])
+def test_ln_modulate_mx8(dev, h):
     from oracle.mmdit import affine_transform
-    B, S, h = 2, 192, 1024
+    B, S = 2, 192
     x = randn(B * S, h, seed=1, scale=1.5)
     shift, scale = randn(B, h, seed=2, scale=0.3), randn(B, h, seed=3, scale=0.3)
     q, sc = ops.ln_modulate_mx8(x.to(dev, BF), shift.to(dev, BF), scale.to(dev, BF), mod_seg_len=S)
