@@ -247,8 +247,9 @@ static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   // of a K = 1536 tile's time, and its per-row tail path (ragged M: SD3's 2 x 589 text rows) is slower still -- SD3-medium in the model:
   // every eligible launch 22.0 against 21.5 ms per step, launches of whole 256-row tiles only (the image stream's fc1) 21.2
   // (profiles/r05_gemm_v4_in_model.log).  ("gemm_v4" 2: lab, no such restriction)
+  // (ragged launches stay on gemm256v3.hip whatever K: the lab's 1178 x 6144 x 1536 text fc1 takes 80 us here against 49 there)
   const bool ragged = a.M % 256 != 0 || (b != nullptr && b->M % 256 != 0);
-  if (a.K < 2048 && ragged && g_dk_v4_auto != 2) return false;
+  if (ragged && g_dk_v4_auto != 2) return false;
   long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
   if (b) tiles += (long)((b->M + 255) / 256) * (b->N / 256);
   const long frac = tiles % 256;

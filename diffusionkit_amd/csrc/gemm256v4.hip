@@ -41,6 +41,19 @@ __device__ __forceinline__ int v4_xcd_contiguous(int bid, int count) {
   return start + (bid >> 3);
 }
 
+#ifndef V4_NT
+#define V4_NT 0  // lab: cache policy of the C stores -- 0 plain (L2 write-back), 1 non-temporal (nt), 2 write-through to memory (sc0 sc1)
+#endif
+__device__ __forceinline__ void v4_store16(bf16_t* ptr, u32x4 v) {
+#if V4_NT == 1
+  __builtin_nontemporal_store(v, (u32x4*)ptr);
+#elif V4_NT == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+#else
+  *(u32x4*)ptr = v;
+#endif
+}
+
 struct V4Tail {
   const GemmParams __attribute__((address_space(4))) * p;
   bf16_t* Cb;
@@ -172,7 +185,7 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       }
       const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((v4_lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
       if (PLAIN) {
-        if (FAST || valid) *(u32x4*)(t.Cb + crow * (size_t)t.ldcb + ocol) = sv;
+        if (FAST || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, sv);
         continue;
       }
       float vv[8];
@@ -223,7 +236,7 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       o4.y = pack2bf(vv[2], vv[3]);
       o4.z = pack2bf(vv[4], vv[5]);
       o4.w = pack2bf(vv[6], vv[7]);
-      if (FAST || valid) *(uint4*)(t.Cb + crow * (size_t)t.ldcb + ocol) = o4;
+      if (FAST || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, u32x4{o4.x, o4.y, o4.z, o4.w});
     }
   }
 }

@@ -91,7 +91,23 @@ def wait(vm=None, lgkm=None):
 BARRIER = lambda: I("barrier", "s_barrier")  # noqa: E731
 
 
-def body(dma_on, next_on, outstanding_next, phase=None, nbar=4):
+def drain_tile(nf8, mfi, slot):
+    """bf16(alpha * acc + bias) of accumulator tile (nf8, mfi) into the staging image; temporaries v[32 + 4 * slot : +4]"""
+    vwn, ni, nf = nf8 >> 2, (nf8 >> 1) & 1, nf8 & 1
+    a = (nf8 * 8 + mfi) * 4
+    r = 32 + (slot % 8) * 4
+    out = [I("acc_read", f"v_accvgpr_read_b32 v{r + e}, a{a + e}", dst=r + e, src=a + e) for e in range(4)]
+    b = BIAS0 + nf8 * 4
+    out.append(I("pk_fma", f"v_pk_fma_f32 v[{r}:{r + 1}], s[72:73], v[{r}:{r + 1}], v[{b}:{b + 1}]", dst=r, x=r, b=b))
+    out.append(I("pk_fma", f"v_pk_fma_f32 v[{r + 2}:{r + 3}], s[72:73], v[{r + 2}:{r + 3}], v[{b + 2}:{b + 3}]", dst=r + 2, x=r + 2, b=b + 2))
+    out.append(I("cvt_pk", f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", dst=r, lo=r, hi=r + 1))
+    out.append(I("cvt_pk", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}", dst=r + 1, lo=r + 2, hi=r + 3))
+    off = vwn * 16384 + ni * 8192 + mfi * 1024
+    out.append(I("ds_write", f"ds_write_b64 v{24 + nf}, v[{r}:{r + 1}] offset:{off}", addr=24 + nf, src=r, off=off))
+    return out
+
+
+def body(dma_on, next_on, outstanding_next, phase=None, nbar=4, drain=False):
     """one K-tile.  dma_on: issue the pieces of K-tile i + 2; next_on: read the first slice of K-tile i + 1 at the end;
     outstanding_next: own pieces of K-tile i + 1 that may still be in flight at the head of this body (16, X before W);
     phase: None = every wave issues its DMA pieces at the same MFMA slots; w = this is wave w's copy of the body, pieces 4 slots apart
@@ -170,6 +186,15 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4):
         issued = sum(1 for mm in range(m + 1) for ins in slots[mm] if ins.op == "dma")
         keep = issued + (8 if (o == "X" and outstanding_next == 16) else 0)
         slots[m].append(wait(vm=keep))
+    if drain:
+        # last K-tile of the tile (no DMA, no next reads): behind its second release barrier every wave has read everything it will ever
+        # read of the ring, so the staging image may be written; the second-slice MFMAs of weight fragment j (m = 64 + 8j ..) finish the
+        # accumulator tiles (j, 0..7) -- they are drained under the MFMAs of fragment j + 1 (one tile per MFMA gap, >= 8 MFMAs behind the
+        # one that wrote it; temporaries = the dead first-slice X registers).  Row 7 is drained behind the loop.
+        assert not dma_on and not next_on and nbar == 4
+        for j in range(7):
+            for g in range(8):
+                put(64 + 8 * (j + 1) + g, drain_tile(j, g, g))
     out = []
     for m in range(128):
         out.extend(slots[m])
@@ -180,7 +205,9 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4):
     return out
 
 
-def program(nbar=4, stagger=False, trace=False):
+def program(nbar=4, stagger=False, trace=False, drain_overlap=None):
+    if drain_overlap is None:
+        drain_overlap = nbar == 4
     """trace (lab): s_memtime stamps in s[74:75] (first DMA piece issued), s[76:77] (first K-tile landed, barrier passed), s[78:79] (K loop
     done), s[80:81] (drain done) -- read back by the -DV4_TRACE build of gemm256v4.hip"""
     P = []
@@ -262,30 +289,20 @@ def program(nbar=4, stagger=False, trace=False):
         P.append(I("cbranch_scc1", f"s_cbranch_scc1 {L(3)}f", target=f"L22_{c}"))
         P.extend(body(False, True, 16, w, nbar))
         P.append(I("label", f"{L(3)}:", name=f"L22_{c}"))
-        P.extend(body(False, False, 0, w, nbar))
+        P.extend(body(False, False, 0, w, nbar, drain=drain_overlap))
         if w is not None and w != copies[-1]:
             P.append(I("branch", "s_branch 90f", target="DRAIN"))
     P.append(I("label", "90:", name="DRAIN"))
     P.extend(stamp(78))
-    # ---- drain: bf16(alpha * acc + bias) into the staging image (every wave is past the last body's release barrier(s): ring free)
-    P.append(BARRIER())
-    t = 32  # temporaries v[32:..] (the fragment registers are dead)
+    # ---- drain: bf16(alpha * acc + bias) into the staging image.  With drain_overlap seven of the eight accumulator rows left under the
+    # last K-tile's MFMAs; otherwise every wave is past the last body's release barriers and one more barrier frees the ring
+    if not drain_overlap:
+        P.append(BARRIER())
     n = 0
-    for nf8 in range(8):
-        vwn, ni, nf = nf8 >> 2, (nf8 >> 1) & 1, nf8 & 1
+    for nf8 in range(7 if drain_overlap else 0, 8):
         for mfi in range(8):
-            a = (nf8 * 8 + mfi) * 4
-            r = t + (n % 8) * 4
+            P.extend(drain_tile(nf8, mfi, n))
             n += 1
-            for e in range(4):
-                P.append(I("acc_read", f"v_accvgpr_read_b32 v{r + e}, a{a + e}", dst=r + e, src=a + e))
-            b = BIAS0 + nf8 * 4
-            P.append(I("pk_fma", f"v_pk_fma_f32 v[{r}:{r + 1}], s[72:73], v[{r}:{r + 1}], v[{b}:{b + 1}]", dst=r, x=r, b=b))
-            P.append(I("pk_fma", f"v_pk_fma_f32 v[{r + 2}:{r + 3}], s[72:73], v[{r + 2}:{r + 3}], v[{b + 2}:{b + 3}]", dst=r + 2, x=r + 2, b=b + 2))
-            P.append(I("cvt_pk", f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", dst=r, lo=r, hi=r + 1))
-            P.append(I("cvt_pk", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}", dst=r + 1, lo=r + 2, hi=r + 3))
-            off = vwn * 16384 + ni * 8192 + mfi * 1024
-            P.append(I("ds_write", f"ds_write_b64 v{24 + nf}, v[{r}:{r + 1}] offset:{off}", addr=24 + nf, src=r, off=off))
     P.append(wait(lgkm=0))
     P.extend(stamp(80))
     if trace:
