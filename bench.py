@@ -303,6 +303,24 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
             _lib.check(lib.dk_profile_read(cls_id, C.byref(ms), C.byref(work), C.byref(n)), "dk_profile_read")
             stats[name] = (ms.value, work.value, n.value)
         lib.dk_profile_enable(0)
+        # same-box reference for the round-5 kernel choice: the same replay with generation 3 (gemm256v3.hip) on every block Linear -- boxes of
+        # the pool differ by several per cent, this pair of numbers does not (bf16 headline workload only: one more second)
+        gen3 = None
+        if not fp8 and workload == "flux-schnell-1024" and B == 1:
+            _lib.check(lib.dk_tune_set(b"gemm_v4", 0), "dk_tune_set")
+            try:
+                one_image(rank * 100000)  # warm
+                lib.dk_profile_enable(1)
+                for i in range(n_replay):
+                    one_image(rank * 100000 + i)
+                torch.cuda.synchronize()
+                ms3, work3, n3 = C.c_double(), C.c_double(), C.c_int64()
+                _lib.check(lib.dk_profile_read(0, C.byref(ms3), C.byref(work3), C.byref(n3)), "dk_profile_read")
+                gen3 = {"achieved": round(work3.value / max(ms3.value, 1e-9) / 1e9, 1), "gemm_ms_per_image": round(ms3.value / n_replay / B, 2),
+                        "what": "the same replay with dk_tune_set(gemm_v4, 0): gemm256v3.hip on every block Linear (round 4's kernel choice)"}
+            finally:
+                lib.dk_profile_enable(0)
+                _lib.check(lib.dk_tune_set(b"gemm_v4", -1), "dk_tune_set")
         dom = "gemm_fp8" if fp8 else "gemm"
         peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
         ms, work, n = stats[dom]
@@ -338,6 +356,9 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
         }
         if fp8:
             roofline["bf16_gemm"] = sub("gemm")
+        if gen3 is not None:
+            gen3["frac"] = round(gen3["achieved"] / peak, 4)
+            roofline["same_box_generation3_only"] = gen3
 
     res = None
     if rank == 0:

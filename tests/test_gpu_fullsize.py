@@ -396,9 +396,9 @@ CLOSED_TOL = {
     # (profiles/r05_fullsize_parity.log); the intermediate latents are printed (how the distance grows along the trajectory)
     "sd3_full_50": (49.5, 1.53e-2),     # measured 51.52 dB / 1.018e-2 after 50 steps (78.6 dB after step 1, 65.3 after 10, 56.5 after 30: rel-L2 grows ~ linearly)
     "sd3_full_50_image": (44.4, None),  # measured 46.41 dB with the reference's own image metric (its gate for a trained model: 20 dB, tests/mlx/test_diffusion_pipeline.py:20)
-    "flux_dev_10": (0.0, 1e9),
-    "flux_dev_10_fp8": (0.0, 1e9),
-    "flux_dev_10_fp8_policy": (0.0, 1e9),
+    "flux_dev_10": (54.4, 1.01e-2),             # measured 56.49 dB / 6.73e-3 (bf16 weights, 10 closed-loop steps, sigma 1 -> 0)
+    "flux_dev_10_fp8": (36.8, 7.7e-2),           # measured 38.83 dB / 5.14e-2 (every block Linear in fp8: ten ~32 dB steps)
+    "flux_dev_10_fp8_policy": (40.9, 4.8e-2),    # measured 42.93 dB / 3.21e-2 (the shipped precision policy: first 12 double blocks bf16)
 }
 
 
