@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   if (getenv("LAB_SPLIT")) dk_tune_set("gemm_split", atoi(getenv("LAB_SPLIT")));
+  if (getenv("LAB_MF")) dk_tune_set("gemm_mf", atoi(getenv("LAB_MF")));  // gemm256v3.hip tile height: 8 / 7 (224-row tiles), -1 automatic
   if (getenv("LAB_SKEW")) dk_tune_set("gemm_skew", atoi(getenv("LAB_SKEW")));  // gemm256v4.hip: start skew of multi-round launches, 0.25 us steps  // v3 remainder-wave K split: -1 auto, 0 off, 1 force
   void* ws = nullptr;
   const size_t ws_bytes = dk_gemm_workspace_bytes();

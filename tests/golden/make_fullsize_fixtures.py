@@ -424,6 +424,29 @@ def make_sd3_full_50():
     return out
 
 
+def make_sd3_full_50_emu():
+    """context for the closed-loop row (round 5): the bf16-EMULATING oracle (the reference's MLX rounding points) over the same 50 steps,
+    measured against the fp32 trajectory of fullsize_sd3_full_50.npz -- added to that file as emu_psnr / emu_rel_l2 (final latent) and
+    emu_psnr_step<k> for the kept steps (~2 h on 8 cores)"""
+    c = SD3_FULL_50
+    cfg = c["cfg"]
+    path = os.path.join(HERE, "fullsize_sd3_full_50.npz")
+    old = dict(np.load(path))
+    w = {k: v.float() for k, v in synth_mmdit_weights(cfg, seed=c["seed_w"]).items()}
+    text, pooled = sd3_full_inputs()
+    x0, sig = sd3_full_start(c)
+    trace = ProgressTrace("sd3_full_50 emu", time.time())
+    last = op.sample_euler(ref_model(cfg, w, Prec(BF)), x0, sig, text, pooled, c["cfg_weight"], Prec(BF), trace, t_act=Prec(torch.float16))
+    for k in c["keep"]:
+        ref = torch.from_numpy(old["x_step50_fp32"] if k == 50 else old[f"x_step{k}_f16"].astype(np.float32))
+        old[f"emu_psnr_step{k}"] = np.float64(psnr(ref, trace[k - 1]))
+    ref = torch.from_numpy(old["x_step50_fp32"])
+    old["emu_psnr"] = np.float64(psnr(ref, last))
+    old["emu_rel_l2"] = np.float64(rel_l2(ref, last))
+    print({k: float(v) for k, v in old.items() if k.startswith("emu")}, flush=True)
+    return old
+
+
 class ProgressTrace(list):
     def __init__(self, name, t0):
         super().__init__()
@@ -457,7 +480,7 @@ def make_flux_dev_10():
     return out
 
 
-CASES = {"sd3_full_50": make_sd3_full_50, "flux_dev_10": make_flux_dev_10, "flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
+CASES = {"sd3_full_50": make_sd3_full_50, "sd3_full_50_emu": make_sd3_full_50_emu, "flux_dev_10": make_flux_dev_10, "flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
          "flux_1024": lambda: make_forward(FLUX_1024, "flux_1024"), "flux_full": make_flux_full,
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,
