@@ -68,6 +68,8 @@ int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t s
 extern int g_dk_v4_auto;  // gemm.hip
 extern int g_dk_v4_skew;  // gemm256v4.hip
 bool dk_gemm256v4_eligible(const GemmParams& p);
+bool dk_gemm256v4_uniform_tiles(const GemmParams& p, int bm);
+int dk_gemm256v4_pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu);
 int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int tiles_a, int tiles_b, hipStream_t stream);  // gemm256v3.hip (16x16x32 MFMA K loop)
 // two problems with the same N, K, epilogue in one launch (image + text stream of a double block); falls

@@ -243,15 +243,16 @@ static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   if (g_dk_gemm_mode != 10 && (g_dk_gemm_mode != -1 || g_dk_v4_auto == 0)) return false;
   if (!dk_gemm256v4_eligible(a) || (b != nullptr && !dk_gemm256v4_eligible(*b))) return false;
   if (g_dk_gemm_mode == 10) return true;
-  // short reductions: this kernel's fixed cost per tile is ~ 1 us higher (a lone wave drains and writes out the whole 128 x 128 block), a third
-  // of a K = 1536 tile's time, and its per-row tail path (ragged M: SD3's 2 x 589 text rows) is slower still -- SD3-medium in the model:
-  // every eligible launch 22.0 against 21.5 ms per step, launches of whole 256-row tiles only (the image stream's fc1) 21.2
-  // (profiles/r05_gemm_v4_in_model.log).  ("gemm_v4" 2: lab, no such restriction)
-  // (ragged launches stay on gemm256v3.hip whatever K: the lab's 1178 x 6144 x 1536 text fc1 takes 80 us here against 49 there)
-  const bool ragged = a.M % 256 != 0 || (b != nullptr && b->M % 256 != 0);
-  if (ragged && g_dk_v4_auto != 2) return false;
-  long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
-  if (b) tiles += (long)((b->M + 255) / 256) * (b->N / 256);
+  // launches with tiles that straddle row segments or short reductions with ragged rows stay on gemm256v3.hip: this kernel's per-row tail path
+  // is slow (the lab's 1178 x 6144 x 1536 text fc1: 80 us here against 49 there) and its fixed cost per tile ~ 1 us higher (SD3-medium in the
+  // model: every eligible launch 22.0 against 21.5 ms per step, whole-tile launches only 21.2; profiles/r05_gemm_v4_in_model.log).
+  // ("gemm_v4" 2: lab, no such restriction)
+  const int mf = dk_gemm256v4_pick_mf(a, b, 256), bm = 32 * mf;
+  const bool uniform = dk_gemm256v4_uniform_tiles(a, bm) && (b == nullptr || dk_gemm256v4_uniform_tiles(*b, bm));
+  const bool ragged = a.M % bm != 0 || (b != nullptr && b->M % bm != 0);
+  if ((!uniform || (ragged && a.K < 2048)) && g_dk_v4_auto != 2) return false;
+  long tiles = (long)((a.M + bm - 1) / bm) * (a.N / 256);
+  if (b) tiles += (long)((b->M + bm - 1) / bm) * (b->N / 256);
   const long frac = tiles % 256;
   return tiles <= 256 || tiles >= 2048 || frac == 0 || frac > 144;
 }

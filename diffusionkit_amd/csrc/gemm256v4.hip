@@ -64,17 +64,23 @@ struct V4Tail {
 
 // read-back of the staged tile: see gemm256v3.hip (rows lambda); FAST: tile-uniform row maps; EK: epilogue folded at compile time (-1: run time);
 // KF: key / query tile with the fused QKNorm + RoPE
-template <bool FAST, int EK, bool KF>
+// CUT (with FAST): the tile lies inside one segment of every map but M ends inside it (the last row tile: 4352 rows in 224-row tiles) -- the
+// tile-uniform addressing of FAST with a row limit: rows past it are neither stored nor (residual) loaded from their own address
+template <bool FAST, int EK, bool KF, int MF, bool CUT = false>
 __device__ __forceinline__ void v4_rows(const V4Tail& t) {
+  static_assert(FAST || !CUT, "CUT is a form of FAST");
+  constexpr int HROWS = 16 * MF;  // rows of a wave's block (the LDS image keeps 128-row regions; a 224-row tile uses 112 of each)
   const auto& p = *t.p;
   constexpr bool PLAIN = EK == DK_EPI_BIAS && !KF;
   const int lane = t.lane;
   const int rrow = lane >> 2, rc2 = (lane & 3) * 2;
-  const int mrow0 = t.m0 + t.wm * 128;
+  const int mrow0 = t.m0 + t.wm * HROWS;
+  const int row_lim = CUT ? t.p->M - 1 - mrow0 : HROWS;  // last valid row of this wave's block
+  if (CUT && row_lim < 0) return;                        // (the whole block lies past M)
   const int ep = EK >= 0 ? EK : t.epi;
   const bool hres = EK >= 0 ? (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES) : t.has_res;
-  const size_t physC0 = (size_t)((t.m0 / p.c_seg_len) * p.c_seg_stride + (t.m0 % p.c_seg_len)) + t.wm * 128;
-  const size_t physR0 = hres ? (size_t)((t.m0 / p.r_seg_len) * p.r_seg_stride + (t.m0 % p.r_seg_len)) + t.wm * 128 : 0;
+  const size_t physC0 = (size_t)((t.m0 / p.c_seg_len) * p.c_seg_stride + (t.m0 % p.c_seg_len)) + t.wm * HROWS;
+  const size_t physR0 = hres ? (size_t)((t.m0 / p.r_seg_len) * p.r_seg_stride + (t.m0 % p.r_seg_len)) + t.wm * HROWS : 0;
   const bf16_t* gate_row = ep == DK_EPI_GATE_RES ? p.gate + (size_t)(t.m0 / p.gate_seg_len) * p.gate_stride : nullptr;
   auto unpack8 = [](const uint4 v, float* f) {
     unpack2bf(v.x, f[0], f[1]);
@@ -84,16 +90,16 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
   };
   // KF: sum of squares of every row over its head's columns, from the staged (bf16-rounded) values: this lane's 8 rows, per head
   // (kn_D = 128: the wave's 128 columns are one head; 64: two heads = the two virtual waves)
-  float ss[2][8];
+  float ss[2][MF];
   if (KF) {
 #pragma unroll
     for (int vwn = 0; vwn < 2; ++vwn) {
 #pragma unroll
-      for (int itr = 0; itr < 8; ++itr) ss[vwn][itr] = 0.f;
+      for (int itr = 0; itr < MF; ++itr) ss[vwn][itr] = 0.f;
       for (int ni = 0; ni < 2; ++ni) {
         const unsigned reg0 = (unsigned)((t.wm * 4 + 2 * t.wn2 + vwn) * 16384 + ni * 8192);
 #pragma unroll
-        for (int itr = 0; itr < 8; ++itr) {
+        for (int itr = 0; itr < MF; ++itr) {
           const int row = itr * 16 + rrow;
           const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((v4_lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
           float vv[8];
@@ -103,14 +109,14 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
         }
       }
 #pragma unroll
-      for (int itr = 0; itr < 8; ++itr) {
+      for (int itr = 0; itr < MF; ++itr) {
         ss[vwn][itr] += __shfl_xor(ss[vwn][itr], 1, 64);
         ss[vwn][itr] += __shfl_xor(ss[vwn][itr], 2, 64);
       }
     }
     if (p.kn_D == 128) {
 #pragma unroll
-      for (int itr = 0; itr < 8; ++itr) ss[0][itr] = ss[1][itr] = ss[0][itr] + ss[1][itr];
+      for (int itr = 0; itr < MF; ++itr) ss[0][itr] = ss[1][itr] = ss[0][itr] + ss[1][itr];
     }
   }
   // FAST tiles: everything the rows read from memory is fetched before the first store -- for all four passes at once (the residual is
@@ -118,8 +124,8 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
   // round trip; gemm256v3.hip round 4 did this per pass)
   constexpr bool PRE_RES = FAST && (EK == DK_EPI_GATE_RES || EK == DK_EPI_RES);
   constexpr bool PRE_ROPE = FAST && KF;
-  uint4 res_pre[PRE_RES ? 4 : 1][PRE_RES ? 8 : 1];
-  f32x4 rope_pre[PRE_ROPE ? 4 : 1][PRE_ROPE ? 16 : 1];
+  uint4 res_pre[PRE_RES ? 4 : 1][PRE_RES ? MF : 1];
+  f32x4 rope_pre[PRE_ROPE ? 4 : 1][PRE_ROPE ? 2 * MF : 1];
   float gate_pre[(FAST && EK == DK_EPI_GATE_RES) ? 4 : 1][8];
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -127,14 +133,14 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
     const int col = t.n0 + wn * 64 + ni * 32 + rc2 * 4;
     if (PRE_RES) {
 #pragma unroll
-      for (int itr = 0; itr < 8; ++itr) res_pre[pass][itr] = *(const uint4*)(p.res + (physR0 + itr * 16 + rrow) * (size_t)p.ldr + col);
+      for (int itr = 0; itr < MF; ++itr) res_pre[pass][itr] = *(const uint4*)(p.res + (physR0 + (CUT ? min(itr * 16 + rrow, row_lim) : itr * 16 + rrow)) * (size_t)p.ldr + col);
     }
     if (FAST && EK == DK_EPI_GATE_RES) unpack8(*(const uint4*)(gate_row + col), gate_pre[pass]);
     if (PRE_ROPE) {
       if (p.kn_rope != nullptr) {
         const int kcol = col % p.kn_D;
 #pragma unroll
-        for (int itr = 0; itr < 8; ++itr) {
+        for (int itr = 0; itr < MF; ++itr) {
           const int kpos_ = (mrow0 + itr * 16 + rrow) % p.kn_seg_len;
           const float* tab = p.kn_rope + ((size_t)(p.kn_pos_off + kpos_) * (size_t)(p.kn_D / 2) + (size_t)(kcol >> 1)) * 2;
           rope_pre[pass][2 * itr] = *(const f32x4*)tab, rope_pre[pass][2 * itr + 1] = *(const f32x4*)(tab + 4);
@@ -167,10 +173,10 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       if (ep == DK_EPI_GATE_RES) g_seg = ms / p.gate_seg_len, g_rem = ms % p.gate_seg_len;
     }
 #pragma unroll
-    for (int itr = 0; itr < 8; ++itr) {
+    for (int itr = 0; itr < MF; ++itr) {
       const int row = itr * 16 + rrow;  // row inside the wave's block of 128 rows
       size_t crow = physC0 + row, rrow_phys = physR0 + row;
-      bool valid = true;
+      bool valid = !CUT || row <= row_lim;
       const int kpos = KF ? (mrow0 + row) % p.kn_seg_len : 0;
       if (!FAST) {
         valid = mrow0 + row < p.M;
@@ -185,7 +191,7 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       }
       const u32x4 sv = *(const __attribute__((address_space(3))) u32x4*)((v4_lds_char*)0 + reg0 + row * 64 + ((((unsigned)rc2 >> 1) ^ ((unsigned)(row >> 2) & 3u)) << 4));
       if (PLAIN) {
-        if (FAST || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, sv);
+        if ((FAST && !CUT) || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, sv);
         continue;
       }
       float vv[8];
@@ -236,12 +242,16 @@ __device__ __forceinline__ void v4_rows(const V4Tail& t) {
       o4.y = pack2bf(vv[2], vv[3]);
       o4.z = pack2bf(vv[4], vv[5]);
       o4.w = pack2bf(vv[6], vv[7]);
-      if (FAST || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, u32x4{o4.x, o4.y, o4.z, o4.w});
+      if ((FAST && !CUT) || valid) v4_store16(t.Cb + crow * (size_t)t.ldcb + ocol, u32x4{o4.x, o4.y, o4.z, o4.w});
     }
   }
 }
 
+// MF: 16-row activation fragments per wave: 8 = 256-row tiles, 7 = 224-row tiles (the launcher takes the height with the fewest rounds x height,
+// gemm256v3.hip's rule: 4352 rows x 12 column tiles are 204 tiles of 256 rows -- 80 % of the CUs -- or 240 of 224)
+template <int MF>
 __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, GemmParams pb, int tiles_a, int tiles_b, int skew) {
+  constexpr int BM = 32 * MF, HROWS = 16 * MF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(v4_lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
   // Start skew (multi-round launches): the first round's workgroups start up to `skew` x 0.25 us apart (by their position inside their
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   const __attribute__((address_space(4))) char* kbase = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
   karg_params_t& p = *(karg_params_t*)(kbase + (second ? sizeof(GemmParams) : 0));
   const int tl = second ? tile - tiles_a : tile;
-  const int nbm = (p.M + V4_T - 1) / V4_T, nbn = p.N / V4_T;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / V4_T;
   const int GROUP = 4;
   const int tpg = GROUP * nbn;
   const int g = tl / tpg;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   const int gsz = min(nbm - first_m, GROUP);
   const int tm = first_m + (tl % tpg) % gsz;
   const int tn = (tl % tpg) / gsz;
-  const int m0 = tm * V4_T, n0 = tn * V4_T;
+  const int m0 = tm * BM, n0 = tn * V4_T;
 
   // ---- DMA piece offsets: piece gg of a wave covers rows hh*128 + (wave*2 + u)*16 + j*8 + (lane >> 3) of the operand's 256-row K-tile,
   // 16-byte chunk (lane & 7) of LDS row r holds global chunk (lane & 7) ^ ((r >> 1) & 7) (conflict-free ds_read_b128, gemm256v3.hip)
@@ -282,14 +292,16 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   // (a tile that lies inside one row segment -- every tile of the image stream -- maps its rows with one scalar division instead of eight
   //  per lane: the integer divisions were ~ 0.4 us in front of the first DMA piece of every tile)
   const int a_seg0 = m0 / p.a_seg_len;
-  const bool a_uniform = min(m0 + V4_T - 1, p.M - 1) / p.a_seg_len == a_seg0;
+  const bool a_uniform = min(m0 + BM - 1, p.M - 1) / p.a_seg_len == a_seg0;
   const int a_base = a_seg0 * p.a_seg_stride - a_seg0 * p.a_seg_len;
 #pragma unroll
   for (int gg = 0; gg < 8; ++gg) {
     const int hh = gg & 1, j = (gg >> 1) & 1, u = gg >> 2;
-    const int row = hh * 128 + (wave * 2 + u) * 16 + j * 8 + srow;
+    const int rih = (wave * 2 + u) * 16 + j * 8 + srow;  // row inside the 128-row LDS half
+    const int row = hh * 128 + rih;
     const int chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j);
-    voX[gg] = (unsigned)min(m0 + row, p.M - 1);  // rows beyond M - 1 re-read the last row, their results are never stored
+    // rows beyond M - 1 re-read the last row, their results are never stored; MF = 7: LDS rows 112 .. 127 of a half hold duplicates nobody reads
+    voX[gg] = (unsigned)min(m0 + hh * HROWS + min(rih, HROWS - 1), p.M - 1);
     voW[gg] = ((unsigned)row * (unsigned)p.ldw + chunk * 8) * 2u;
   }
   if (a_uniform) {  // (a scalar branch: the divisions below are not executed)
@@ -353,6 +365,16 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
 #include "gemm256v4_clobbers.inc"
   );
 #else
+  if constexpr (MF == 7) {
+    asm volatile(
+#include "gemm256v4_asm7.inc"
+        :
+        : [koff] "s"(0), [nk] "s"(nk), [dstx] "s"(wave * 4096), [alpha] "s"(alpha), [wave] "s"(wave), "{v[0:7]}"(voX), "{v[8:15]}"(voW), "{v[16:19]}"(rd),
+          "{v[24:25]}"(dr), "{v[160:167]}"(bq[0]), "{v[168:175]}"(bq[1]), "{v[176:183]}"(bq[2]), "{v[184:191]}"(bq[3]), "{s[60:63]}"(rX), "{s[64:67]}"(rW)
+        :
+#include "gemm256v4_clobbers.inc"
+    );
+  } else
   asm volatile(
 #include "gemm256v4_asm.inc"
       :
@@ -374,22 +396,32 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
   t.ncol0 = out2 ? n0 - p.n_split : n0;
   t.m0 = m0, t.wm = wm, t.wn2 = wn2, t.lane = lane;
   t.has_res = t.epi == DK_EPI_GATE_RES || t.epi == DK_EPI_RES;
-  auto inside = [&](int len) { return m0 / len == (m0 + V4_T - 1) / len; };
-  const bool fast = m0 + V4_T <= p.M && inside(p.c_seg_len) && (!t.has_res || inside(p.r_seg_len)) && (t.epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
+  auto inside = [&](int len) { return m0 / len == (m0 + BM - 1) / len; };
+  const bool fast = m0 + BM <= p.M && inside(p.c_seg_len) && (!t.has_res || inside(p.r_seg_len)) && (t.epi != DK_EPI_GATE_RES || inside(p.gate_seg_len));
   const bool qtile = p.qn_w != nullptr && n0 >= p.qn_col0 && n0 < p.qn_col1;
   const bool kfuse = p.kn_w != nullptr && ((n0 >= p.kn_col0 && n0 < p.kn_col1) || qtile);
   t.nw = qtile ? p.qn_w : p.kn_w;
+  // the last row tile of a single-segment problem: tile-uniform maps, M ends inside it
+  auto inside_cut = [&](int len) { return m0 / len == (p.M - 1) / len; };
+  const bool cut = !fast && m0 + BM > p.M && inside_cut(p.c_seg_len) && (!t.has_res || inside_cut(p.r_seg_len)) &&
+                   (t.epi != DK_EPI_GATE_RES || inside_cut(p.gate_seg_len));
   if (kfuse) {  // (bias-only epilogue -- checked by the launcher)
-    if (fast) v4_rows<true, DK_EPI_BIAS, true>(t);
-    else v4_rows<false, DK_EPI_BIAS, true>(t);
+    if (fast) v4_rows<true, DK_EPI_BIAS, true, MF>(t);
+    else if (cut) v4_rows<true, DK_EPI_BIAS, true, MF, true>(t);
+    else v4_rows<false, DK_EPI_BIAS, true, MF>(t);
+  } else if (cut) {
+    if (t.epi == DK_EPI_BIAS) v4_rows<true, DK_EPI_BIAS, false, MF, true>(t);
+    else if (t.epi == DK_EPI_BIAS_GELU) v4_rows<true, DK_EPI_BIAS_GELU, false, MF, true>(t);
+    else if (t.epi == DK_EPI_GATE_RES) v4_rows<true, DK_EPI_GATE_RES, false, MF, true>(t);
+    else v4_rows<false, -1, false, MF>(t);
   } else if (fast) {
-    if (t.epi == DK_EPI_BIAS) v4_rows<true, DK_EPI_BIAS, false>(t);
-    else if (t.epi == DK_EPI_BIAS_GELU) v4_rows<true, DK_EPI_BIAS_GELU, false>(t);
-    else if (t.epi == DK_EPI_GATE_RES) v4_rows<true, DK_EPI_GATE_RES, false>(t);
-    else if (t.epi == DK_EPI_RES) v4_rows<true, DK_EPI_RES, false>(t);
-    else v4_rows<true, -1, false>(t);
+    if (t.epi == DK_EPI_BIAS) v4_rows<true, DK_EPI_BIAS, false, MF>(t);
+    else if (t.epi == DK_EPI_BIAS_GELU) v4_rows<true, DK_EPI_BIAS_GELU, false, MF>(t);
+    else if (t.epi == DK_EPI_GATE_RES) v4_rows<true, DK_EPI_GATE_RES, false, MF>(t);
+    else if (t.epi == DK_EPI_RES) v4_rows<true, DK_EPI_RES, false, MF>(t);
+    else v4_rows<true, -1, false, MF>(t);
   } else {
-    v4_rows<false, -1, false>(t);
+    v4_rows<false, -1, false, MF>(t);
   }
 #ifdef V4_TRACE
   if (p.workspace != nullptr && wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
@@ -398,6 +430,30 @@ __global__ __launch_bounds__(256, 1) void dk_gemm256v4_kernel(GemmParams pa, Gem
     o[0] = t_entry; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = __builtin_readcyclecounter();
   }
 #endif
+}
+
+// Tile height of a launch: gemm256v3.hip's rule (rounds of the CUs x rows per tile over both problems; 224-row tiles only for long reductions and
+// only when the model predicts at least 10 %; dk_tune_set("gemm_mf", 7 | 8) forces one)
+// every row tile of height bm lies inside one segment of every row map (tile-uniform tail paths: FAST, or CUT for the last one)
+bool dk_gemm256v4_uniform_tiles(const GemmParams& p, int bm) {
+  auto ok = [&](int len) { return len >= p.M || len % bm == 0; };
+  const bool res = p.epi == DK_EPI_GATE_RES || p.epi == DK_EPI_RES || (p.n_split > 0 && (p.epi2 == DK_EPI_GATE_RES || p.epi2 == DK_EPI_RES));
+  const bool gate = p.epi == DK_EPI_GATE_RES || (p.n_split > 0 && p.epi2 == DK_EPI_GATE_RES);
+  return ok(p.a_seg_len) && ok(p.c_seg_len) && (!res || ok(p.r_seg_len)) && (!gate || ok(p.gate_seg_len)) && (p.kn_w == nullptr || ok(p.kn_seg_len));
+}
+
+int dk_gemm256v4_pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
+  if (g_dk_v3_mf == 7 || g_dk_v3_mf == 8) return g_dk_v3_mf;
+  if (p.K < 2048) return 8;
+  if (!dk_gemm256v4_uniform_tiles(p, 224) || (p2 && !dk_gemm256v4_uniform_tiles(*p2, 224))) return 8;  // (the per-row tail path is slow here)
+  long cost[2];
+  for (int mf = 7; mf <= 8; ++mf) {
+    const int bm = 32 * mf;
+    long tiles = (long)((p.M + bm - 1) / bm) * (p.N / 256);
+    if (p2) tiles += (long)((p2->M + bm - 1) / bm) * (p2->N / 256);
+    cost[mf - 7] = ((tiles + n_cu - 1) / n_cu) * bm;
+  }
+  return cost[0] * 10 <= cost[1] * 9 ? 7 : 8;
 }
 
 int g_dk_v4_skew = -1;  // dk_tune_set("gemm_skew", v): start skew of multi-round launches in 0.25 us steps; -1 (default): none
@@ -419,24 +475,29 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
                "grouped GEMM: N, K, epilogue must match");
   }
   static DkDeviceOnce attr_once;
+  static int n_cu = 256;
   if (attr_once.first()) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
+    int dev = 0;
+    DK_CHECK_HIP(hipGetDevice(&dev));
+    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_once.mark();
   }
-  const int tiles_a = ((p.M + 255) / 256) * (p.N / 256);
-  const int tiles_b = p2 ? ((p2->M + 255) / 256) * (p2->N / 256) : 0;
+  const int mf = dk_gemm256v4_pick_mf(p, p2, n_cu);
+  const int bm = 32 * mf;
+  const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / 256);
+  const int tiles_b = p2 ? ((p2->M + bm - 1) / bm) * (p2->N / 256) : 0;
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);
-  // start skew: only where there is a second round to inherit it, and (automatic choice) only when the last round is a partial one -- the CUs
-  // that start first take its tiles, so the spread costs nothing there (profiles/r05_gemm_v4_start_skew.log: linear1 -1.4 %, the 2.25-round
-  // q / k / v shapes -3 ... -4 %); with a whole number of rounds the launch simply ends `skew` later (+0 ... +1 %)
-  const int tiles = tiles_a + tiles_b, frac = tiles % 256;
-  // ... in the lab with warm weights.  Inside the model (weights from HBM) the same A/B is flat: 58.78 / 58.81 against 58.86 / 58.94 ms per FLUX
+  // ... in the lab with warm weights.  Inside the model (weights from HBM) the start skew is flat: 58.78 / 58.81 against 58.86 / 58.94 ms per FLUX
   // step (profiles/r05_gemm_v4_start_skew.log) -- the automatic choice keeps it off; dk_tune_set("gemm_skew", n) turns it on
-  (void)frac;
-  const int skew = tiles <= 256 || g_dk_v4_skew < 0 ? 0 : g_dk_v4_skew;
-  hipLaunchKernelGGL(dk_gemm256v4_kernel, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
+  const int skew = tiles_a + tiles_b <= 256 || g_dk_v4_skew < 0 ? 0 : g_dk_v4_skew;
+  if (mf == 7)
+    hipLaunchKernelGGL(dk_gemm256v4_kernel<7>, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
+  else
+    hipLaunchKernelGGL(dk_gemm256v4_kernel<8>, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

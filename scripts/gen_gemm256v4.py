@@ -35,6 +35,7 @@ import sys
 import numpy as np
 
 NF = 8
+MFX = 8  # 16-row X (activation) fragments per wave: 8 = 256-row tiles, 7 = 224-row tiles (set by program(mf=...))
 SLOT = 32768
 W_BASE = 65536
 XF = [32, 64]    # first register of X fragment set kk
@@ -113,22 +114,31 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4, drain=False):
     phase: None = every wave issues its DMA pieces at the same MFMA slots; w = this is wave w's copy of the body, pieces 4 slots apart
     and shifted by w (the CU's four waves run in lockstep between barriers: pieces issued at the same slot queue up behind each other);
     nbar: 4 = one release and one landed barrier per operand, 2 = one release and one landed barrier for both."""
-    mf = [mfma(j, k, 0) for j in range(8) for k in range(8)] + [mfma(j, k, 1) for j in range(8) for k in range(8)]
-    slots = [[] for _ in range(129)]  # slots[m] = instructions in front of MFMA m (128 = behind the last one)
+    S = 8 * MFX   # MFMAs per K = 32 slice
+    T = 2 * S     # ... per K-tile
+    mf = [mfma(j, k, 0) for j in range(8) for k in range(MFX)] + [mfma(j, k, 1) for j in range(8) for k in range(MFX)]
+    slots = [[] for _ in range(T + 1)]  # slots[m] = instructions in front of MFMA m (T = behind the last one)
+
+    def pos(p):
+        """slot of the 128-MFMA schedule -> slot of this one: the first 52 slots (second-slice reads, release barriers) keep their place, the
+        rest is compressed linearly (224-row tiles: 112 MFMAs per K-tile)"""
+        if T == 128 or p <= 52:
+            return p
+        return 53 + ((p - 53) * (T - 53)) // (128 - 53)
 
     def put(m, ins):
-        slots[m].extend(ins if isinstance(ins, list) else [ins])
+        slots[pos(m)].extend(ins if isinstance(ins, list) else [ins])
 
     def put_dma(m, o, g):  # (SALU write of M0 -> LDS-DMA needs one wait state: the M0 write sits one MFMA ahead of its piece)
         a, b = dma(o, g)
-        put(m - 1, a)
-        put(m, b)
+        slots[pos(m) - 1].append(a)
+        slots[pos(m)].append(b)
 
     put(0, I("v_xor", f"v_xor_b32 v{RX[1]}, 0x8000, v{RX[1]}", dst=RX[1], imm=0x8000))
     put(0, I("v_xor", f"v_xor_b32 v{RW[1]}, 0x8000, v{RW[1]}", dst=RW[1], imm=0x8000))
     waits = []  # (slot, operand) of the landed waits, filled in below
     if nbar == 4:
-        for k in range(8):
+        for k in range(MFX):
             put(1 + 2 * k, ds_read(XF[1] + 4 * k, RX[1], k * 2048))
         put(20, wait(lgkm=0))
         put(21, BARRIER())  # every wave has read both slices of X(i): its slot is free
@@ -143,21 +153,23 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4, drain=False):
             else:
                 xd = [23 + 4 * g + phase for g in range(8)]       # 23 .. 54
                 wd = [55 + 4 * g + phase for g in range(8)]       # 55 .. 86  (+3)
-            for g in range(8):
+            for g in range(8):  # (all X pieces first: where the compressed 224-row schedule puts an X and a W item into one slot, X's come first)
                 put_dma(xd[g], "X", g)
+            for g in range(8):
                 put_dma(wd[g], "W", g)
         if next_on:
             put(66, I("v_xor", f"v_xor_b32 v{RX[0]}, 0x8000, v{RX[0]}", dst=RX[0], imm=0x8000))
             put(67, I("v_xor", f"v_xor_b32 v{RW[0]}, 0x8000, v{RW[0]}", dst=RW[0], imm=0x8000))
             waits.append((68, "X"))
             put(69, BARRIER())  # X(i + 1) has landed for every wave
-            for k in range(8):
+            for k in range(MFX):
                 put(70 + 2 * k, ds_read(XF[0] + 4 * k, RX[0], k * 2048))
             waits.append((105, "W"))
             put(106, BARRIER())  # W(i + 1) has landed
             for j in range(8):
                 put(107 + j, ds_read(WF[0] + 4 * j, RW[0], j * 2048))
     else:
+        assert MFX == 8
         for k in range(8):
             put(1 + 2 * k, ds_read(XF[1] + 4 * k, RX[1], k * 2048))
             put(2 + 2 * k, ds_read(WF[1] + 4 * k, RW[1], k * 2048))
@@ -178,11 +190,13 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4, drain=False):
                 put(103 + k, ds_read(XF[0] + 4 * k, RX[0], k * 2048))
                 put(111 + k, ds_read(WF[0] + 4 * k, RW[0], k * 2048))
     if dma_on:  # advance the K offset and flip the destination slot for the next iteration (behind the last piece)
-        put(128, I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
-        put(128, I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
-        put(128, I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
+        slots[T].append(I("s_add", "s_add_u32 s68, s68, 128", dst=68, a=68, imm=128))
+        slots[T].append(I("s_xor", "s_xor_b32 s70, s70, 0x8000", dst=70, imm=0x8000))
+        slots[T].append(I("s_xor", "s_xor_b32 s71, s71, 0x8000", dst=71, imm=0x8000))
     # the landed waits: pieces of K-tile i + 2 issued so far in program order may stay in flight; for the X wait W(i + 1)'s 8 as well
     for m, o in waits:
+        m = pos(m)
+        assert not any(ins.op == "barrier" for ins in slots[m]), "a landed wait must sit in front of its barrier's slot"
         issued = sum(1 for mm in range(m + 1) for ins in slots[mm] if ins.op == "dma")
         keep = issued + (8 if (o == "X" and outstanding_next == 16) else 0)
         slots[m].append(wait(vm=keep))
@@ -193,19 +207,22 @@ def body(dma_on, next_on, outstanding_next, phase=None, nbar=4, drain=False):
         # one that wrote it; temporaries = the dead first-slice X registers).  Row 7 is drained behind the loop.
         assert not dma_on and not next_on and nbar == 4
         for j in range(7):
-            for g in range(8):
-                put(64 + 8 * (j + 1) + g, drain_tile(j, g, g))
+            for g in range(MFX):
+                slots[S + MFX * (j + 1) + g].extend(drain_tile(j, g, g))
     out = []
-    for m in range(128):
+    for m in range(T):
         out.extend(slots[m])
         out.append(mf[m])
-    out.extend(slots[128])
+    out.extend(slots[T])
     if next_on:
         out.append(wait(lgkm=0))  # the first slice of the next K-tile
     return out
 
 
-def program(nbar=4, stagger=False, trace=False, drain_overlap=None):
+def program(nbar=4, stagger=False, trace=False, drain_overlap=None, mf=8):
+    global MFX
+    MFX = mf
+    assert mf == 8 or (mf == 7 and nbar == 4 and not stagger)
     if drain_overlap is None:
         drain_overlap = nbar == 4
     """trace (lab): s_memtime stamps in s[74:75] (first DMA piece issued), s[76:77] (first K-tile landed, barrier passed), s[78:79] (K loop
@@ -261,7 +278,7 @@ def program(nbar=4, stagger=False, trace=False, drain_overlap=None):
     # so they start on slot 1
     P.append(I("v_xor", f"v_xor_b32 v{RX[1]}, 0x8000, v{RX[1]}", dst=RX[1], imm=0x8000))
     P.append(I("v_xor", f"v_xor_b32 v{RW[1]}, 0x8000, v{RW[1]}", dst=RW[1], imm=0x8000))
-    for k in range(8):
+    for k in range(MFX):
         P.append(ds_read(XF[0] + 4 * k, RX[0], k * 2048))
     for j in range(8):
         P.append(ds_read(WF[0] + 4 * j, RW[0], j * 2048))
@@ -300,7 +317,7 @@ def program(nbar=4, stagger=False, trace=False, drain_overlap=None):
         P.append(BARRIER())
     n = 0
     for nf8 in range(7 if drain_overlap else 0, 8):
-        for mfi in range(8):
+        for mfi in range(MFX):
             P.extend(drain_tile(nf8, mfi, n))
             n += 1
     P.append(wait(lgkm=0))
@@ -338,6 +355,12 @@ def emit(path, lab_dir=None):
         with open(os.path.join(lab_dir, "gemm256v4_asm_trace.inc"), "w") as f:
             f.write("// GENERATED by scripts/gen_gemm256v4.py --lab: variant 0 with s_memtime stamps in s[74:81]\n")
             f.write("\n".join('    "' + ins.text + '\\n"' for ins in Pt) + "\n")
+    P7 = program(*VARIANTS[0], mf=7)
+    progs.append(P7)
+    with open(path.replace("_asm.inc", "_asm7.inc"), "w") as f:
+        f.write("// GENERATED by scripts/gen_gemm256v4.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
+        f.write(f"// the shipped schedule for 224-row tiles (7 activation fragments per wave, 112 MFMAs per K-tile); {len(P7)} instructions\n")
+        f.write("\n".join('    "' + ins.text + '\\n"' for ins in P7) + "\n")
     with open(path.replace("_asm.inc", "_clobbers.inc"), "w") as f:
         f.write("// GENERATED by scripts/gen_gemm256v4.py\n")
         f.write(", ".join('"' + c + '"' for c in CLOBBERS) + "\n")
@@ -375,7 +398,8 @@ def run(P, nk, late, order, seed=0, verbose=False):
     rng = np.random.default_rng(seed)
     K = nk * 64
     lda, ldw = K + 64, K + 128  # padded pitches
-    Xf = bf16_to_f32(bf16_round(rng.standard_normal((256, lda)).astype(np.float32)))
+    HR = 16 * MFX  # rows of a wave row (of a 128-row LDS half)
+    Xf = bf16_to_f32(bf16_round(rng.standard_normal((2 * HR, lda)).astype(np.float32)))
     Wf = bf16_to_f32(bf16_round(rng.standard_normal((256, ldw)).astype(np.float32) * 0.25))
     bias = bf16_to_f32(bf16_round(rng.standard_normal(256).astype(np.float32)))
     alpha = np.float32(0.5)
@@ -393,9 +417,10 @@ def run(P, nk, late, order, seed=0, verbose=False):
         # piece offsets (host side of the kernel: gemm256v4.hip)
         for g in range(8):
             hh, j, u = g & 1, (g >> 1) & 1, g >> 2
-            row = hh * 128 + (w * 2 + u) * 16 + j * 8 + srow
+            rih = (w * 2 + u) * 16 + j * 8 + srow  # row inside the 128-row LDS half
+            row = hh * 128 + rih
             chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j)
-            wv.V[g] = (row * lda + chunk * 8) * 2
+            wv.V[g] = ((hh * HR + np.minimum(rih, HR - 1)) * lda + chunk * 8) * 2  # (224-row tiles: LDS rows 112-127 of a half hold duplicates nobody reads)
             wv.V[8 + g] = (row * ldw + chunk * 8) * 2
         for kk in range(2):
             offk = l15 * 128 + (((kk * 4 + q) ^ (l15 >> 1)) << 4)
@@ -539,16 +564,16 @@ def run(P, nk, late, order, seed=0, verbose=False):
         land_all(wv, 0)
     # ---- read the staging image back the way the kernel's tail does and compare
     ref = (Xf[:, :K].astype(np.float64) @ Wf[:, :K].astype(np.float64).T) * float(alpha) + bias[None, :].astype(np.float64)
-    got = np.zeros((256, 256), np.float32)
+    got = np.zeros((2 * HR, 256), np.float32)
     for vw in range(8):
         wm, wn = vw >> 2, vw & 3
         for ni in range(2):
             reg0 = vw * 16384 + ni * 8192
-            for row in range(128):
+            for row in range(HR):
                 for ch in range(4):  # 16-byte chunk = 8 columns
                     a = reg0 + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4)
                     vals = lds[a:a + 16].view(np.uint16).astype(np.uint32)
-                    got[wm * 128 + row, wn * 64 + ni * 32 + ch * 8: wn * 64 + ni * 32 + ch * 8 + 8] = bf16_to_f32(vals)
+                    got[wm * HR + row, wn * 64 + ni * 32 + ch * 8: wn * 64 + ni * 32 + ch * 8 + 8] = bf16_to_f32(vals)
     err = np.abs(got - ref) / (np.abs(ref) + 1.0)
     ok = float(err.max()) < 1.2e-2
     if verbose or not ok:
@@ -571,6 +596,7 @@ if __name__ == "__main__":
     if "--check" in sys.argv:
         allok = True
         for v, P in enumerate(progs):
+            MFX = 7 if v == len(progs) - 1 else 8  # (the last one is the 224-row body)
             for nk in (1, 2, 3, 4, 6):
                 for late in (True, False):
                     for order in (0, 1):

@@ -80,3 +80,11 @@ def test_gemm256v4_asm_body_is_the_generators_and_passes_the_emulator():
         for late in (True, False):
             for order in (0, 1):
                 assert gen.run(P, nk, late, order, seed=nk), (nk, late, order)
+    # ... and the body for 224-row tiles (7 activation fragments per wave, 112 MFMAs per K-tile)
+    P7 = gen.program(*gen.VARIANTS[0], mf=7)
+    text7 = "\n".join('    "' + ins.text + '\\n"' for ins in P7) + "\n"
+    committed7 = open(os.path.join(ROOT, "diffusionkit_amd", "csrc", "gemm256v4_asm7.inc")).read()
+    assert committed7.split("\n", 2)[2] == text7, "gemm256v4_asm7.inc is stale: run python scripts/gen_gemm256v4.py"
+    for nk in (1, 2, 3, 4):
+        for late in (True, False):
+            assert gen.run(P7, nk, late, nk & 1, seed=nk), (7, nk, late)

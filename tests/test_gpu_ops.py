@@ -250,12 +250,14 @@ def test_gemm_v3_tile_heights_agree(dev, M, N, K):
     assert torch.equal(outs[8], outs[7]) and torch.equal(outs[8], outs[-1])
 
 
+@pytest.mark.parametrize("mf", [8, 7])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1024, 768, 192), (777, 256, 256), (2048, 1024, 448), (4352, 3072, 3072)])
-def test_gemm_v4_equals_v3(dev, M, N, K, epi):
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1024, 768, 192), (777, 256, 256), (2048, 1024, 448), (4352, 3072, 3072), (224, 256, 128), (4480, 512, 2048)])
+def test_gemm_v4_equals_v3(dev, M, N, K, epi, mf):
     """gemm256v4.hip (one wave per SIMD, asm body: scripts/gen_gemm256v4.py) against gemm256v3.hip: same MFMA, same K order per output
     element, same staged bf16 image and read-back -- bit-identical outputs.  One to 48 K-tiles (1, 2: the peeled bodies only; 3: one
-    pass of the steady-state loop; 7: odd count), ragged M, every fused epilogue; and against the oracle."""
+    pass of the steady-state loop; 7: odd count), ragged M (the last row tile takes the CUT tail path: tile-uniform maps with a row limit),
+    256- and 224-row tiles (gemm_mf 8 / 7: both kernels have both), every fused epilogue; and against the oracle."""
     from diffusionkit_amd import ops
     x, w, b = randn(M, K, seed=70), randn(N, K, seed=71, scale=0.05), randn(N, seed=72, scale=0.1)
     res, gate = randn(M, N, seed=73), randn(1, N, seed=74)
@@ -271,7 +273,7 @@ def test_gemm_v4_equals_v3(dev, M, N, K, epi):
     for mode in (9, 10):
         try:
             ops.tune("gemm", mode)
-            ops.tune("gemm_mf", 8)
+            ops.tune("gemm_mf", mf)
             ops.tune("gemm_split", 0)
             outs[mode] = ops.linear(g(x, dev), g(w, dev), g(b, dev), **kw)
         finally:
