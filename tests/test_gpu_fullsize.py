@@ -435,7 +435,8 @@ def test_sd3_medium_1024_closed_loop_50_steps(dev):
         prev = k
         ref = torch.from_numpy(f["x_step50_fp32"] if k == 50 else f[f"x_step{k}_f16"].astype(np.float32))
         got = x.float().cpu()
-        print(f"[fullsize] sd3_full_50 after step {k:2d}: PSNR {psnr(ref, got):.2f} dB, rel-L2 {rel_l2(ref, got):.3e} (latent rms {float(ref.pow(2).mean().sqrt()):.3f})")
+        emu = f", bf16-emulating oracle {float(f[f'emu_psnr_step{k}']):.2f} dB" if f"emu_psnr_step{k}" in f.files else ""
+        print(f"[fullsize] sd3_full_50 after step {k:2d}: PSNR {psnr(ref, got):.2f} dB, rel-L2 {rel_l2(ref, got):.3e} (latent rms {float(ref.pow(2).mean().sqrt()):.3f}{emu})")
     check_closed("sd3_full_50", torch.from_numpy(f["x_step50_fp32"]), x.float().cpu(), "sd3_full_50")
     img, u8, _ = pipe.decoder.decode(pipe.latent_format.process_out(x))
     p_img = image_psnr(f["image_u8"], u8[0].cpu().numpy())
