@@ -351,8 +351,9 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
         roofline = {
             "bound": "mfma",
             "kernel": ("dk_gemm256f8_kernel (e4m3 x e4m3 block-scaled 16x16x128-MFMA GEMM)" if fp8 else
-                       "dk_gemm256v4_kernel + dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMMs of the block Linears: one wave per SIMD with an asm body for "
-                       "K >= 2048 launches without a small remainder round, the 8-wave kernel for the others; small-M shapes: dk_gemm_bf16_kernel<0>)"),
+                       "dk_gemm256v4_kernel<8 | 7> + dk_gemm256v3_kernel (bf16 16x16x32-MFMA GEMMs of the block Linears: one wave per SIMD with a generated asm body, "
+                       "256- or 224-row tiles, for K >= 2048 launches of segment-uniform tiles -- every block Linear of FLUX; the 8-wave kernel for the others: "
+                       "SD3's K = 1536, SD3.5-large's half column tiles, ragged text rows; small-M shapes: dk_gemm_bf16_kernel<0>)"),
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
