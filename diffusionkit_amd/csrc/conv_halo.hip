@@ -514,6 +514,7 @@ bool dk_conv_halo_eligible(const ConvHaloParams& p, bool img) {
 
 int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream) {
   const bool img = p.img != nullptr || p.u8 != nullptr || p.raw != nullptr;
+  if (!img && dk_conv256v4_wanted(p)) return dk_launch_conv256v4(p, stream);  // the one-wave-per-SIMD frame (conv256v4.hip): 256-column tiles
   DK_REQUIRE(dk_conv_halo_eligible(p, img), "conv_halo: shape / alignment not supported (H, W multiples of 16; C multiple of 64; O multiple of 128, or <= 4 for the image tail)");
   static DkDeviceOnce attr_once;
   constexpr int LDS128 = 2 * CH_A_SLOT + 3 * 128 * 128 + 8192, LDS16 = 2 * CH_A_SLOT + 3 * 16 * 128 + 8192;  // (+ the dummy store zone)

@@ -247,6 +247,12 @@ struct ConvHaloParams {
 };
 bool dk_conv_halo_eligible(const ConvHaloParams& p, bool img);
 int dk_launch_conv_halo(const ConvHaloParams& p, hipStream_t stream);
+// conv256v4.hip: the same contract in the one-wave-per-SIMD frame (16 x 16 pixels x 256 channels per workgroup, asm body); no shortcut
+// extension, no image tail.  dk_launch_conv_halo routes to it when dk_conv256v4_wanted (dk_tune_set("conv_v4", 0 | 1 | 2))
+extern int g_dk_conv_v4;
+bool dk_conv256v4_eligible(const ConvHaloParams& p);
+bool dk_conv256v4_wanted(const ConvHaloParams& p);
+int dk_launch_conv256v4(const ConvHaloParams& p, hipStream_t stream);
 
 // ---- VAE ops -------------------------------------------------------------------------------
 // the second pass of the GroupNorm statistics alone: per (batch, group) the partials [B][nchunk][G][2] -> mean / rstd, and

@@ -47,6 +47,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   if (strcmp(key, "conv_halo") == 0) { g_dk_conv_halo = value; return 0; }
+  if (strcmp(key, "conv_v4") == 0) { g_dk_conv_v4 = value; return 0; }
   dk_set_error(std::string("unknown tuning key: ") + key);
   return -1;
 }
