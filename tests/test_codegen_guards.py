@@ -16,7 +16,7 @@ BUILD = os.path.join(ROOT, "diffusionkit_amd", "csrc", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernels on the denoise / decode path (mangled-name fragments)
-HOT = ["dk_gemm256v4_kernel", "dk_gemm256v3_kernel", "dk_gemm256f8_kernel", "dk_attn4_fwd_kernel", "dk_attn2_fwd_kernel", "dk_attn512_fwd_kernel", "dk_conv_halo_kernel",
+HOT = ["dk_gemm256v4_kernel", "dk_gemm256v3_kernel", "dk_gemm256f8_kernel", "dk_attn4_fwd_kernel", "dk_attn2_fwd_kernel", "dk_attn512_fwd_kernel", "dk_conv_halo_kernel", "dk_conv256v4_kernel",
        "dk_ln_modulate_kernel", "dk_rows_to_mx8_kernel", "dk_euler_step_kernel", "dk_qk_norm_rope_kernel"]
 
 
@@ -55,7 +55,7 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
             seen.add(hot)
             if md.get("vgpr_spill_count", 0) or md.get("sgpr_spill_count", 0) or md.get("private_segment_fixed_size", 0):
                 bad.append((os.path.basename(obj), name, md))
-            if hot == "dk_gemm256v4_kernel":  # one wave per SIMD by design: the 256 accumulators in AGPRs beside at most 256 VGPRs
+            if hot in ("dk_gemm256v4_kernel", "dk_conv256v4_kernel"):  # one wave per SIMD by design: the 256 accumulators in AGPRs beside at most 256 VGPRs
                 assert md["vgpr_count"] <= 512, (name, md)
             else:
                 assert md["vgpr_count"] <= 256, (name, md)  # two waves per SIMD at least
@@ -88,3 +88,27 @@ def test_gemm256v4_asm_body_is_the_generators_and_passes_the_emulator():
     for nk in (1, 2, 3, 4):
         for late in (True, False):
             assert gen.run(P7, nk, late, nk & 1, seed=nk), (7, nk, late)
+
+
+def test_conv256v4_asm_bodies_are_the_generators_and_pass_the_emulator():
+    """conv256v4.hip's two asm bodies (GroupNorm + SiLU on the way into the halo / plain input) are GENERATED (scripts/gen_conv256v4.py): the
+    committed include files must be what the generator writes, and the instruction lists must pass its CPU emulator on a corner tile (every
+    border is padding; two 64-channel chunks: one pass of the chunk loop + the peeled last chunk) with every memory instruction landing as
+    late as its wait allows, or at issue, and the waves in both orders.  Then the emulator itself is checked: with the wait in front of the
+    halo transform weakened, the late run must come out wrong."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_conv256v4 as gen
+    for xform, name in ((True, "x"), (False, "p")):
+        P = gen.program(xform)
+        text = "\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n"
+        committed = open(os.path.join(ROOT, "diffusionkit_amd", "csrc", f"conv256v4_asm_{name}.inc")).read()
+        assert committed.split("\n", 2)[2] == text, f"conv256v4_asm_{name}.inc is stale: run python scripts/gen_conv256v4.py"
+        for late in (True, False):
+            assert gen.run(P, xform, (0, 0), late, int(late), C=128, HWimg=32, seed=5), (xform, late)
+    P = gen.program(True)
+    halo_waits = [i for i in P if i.op == "wait" and "need" in i.kw and i.need[0] == "H"]
+    assert len(halo_waits) >= 2  # prologue + loop body
+    for w in halo_waits:
+        w.kw["vm"] = 63
+    assert not gen.run(P, True, (0, 0), True, 0, C=128, HWimg=32, seed=5), "the emulator did not notice a halo transform running ahead of its loads"

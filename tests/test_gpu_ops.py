@@ -631,6 +631,48 @@ def test_conv3x3_gn_halo(dev, B, H, W, C, O, res, sc, gn):
     assert rel_l2(t_pass.cpu(), t_part.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,O,res,gn,ups", [(1, 16, 16, 128, 256, False, True, False),   # one tile: every border is padding; one pass of the chunk loop
+                                                   (2, 32, 48, 128, 256, True, True, False),    # 12 tiles, two images, residual
+                                                   (1, 48, 48, 256, 512, False, True, False),   # an inner tile, two column tiles, four chunks
+                                                   (1, 32, 32, 512, 256, True, True, False),    # eight chunks
+                                                   (2, 32, 48, 128, 256, False, False, True),   # plain input through the nearest-x2 view
+                                                   (1, 64, 32, 256, 256, True, False, False)])  # plain input, residual
+def test_conv256v4_equals_conv_halo(dev, B, H, W, C, O, res, gn, ups):
+    """conv256v4.hip (one wave per SIMD, 16 x 16 pixels x 256 channels per workgroup, asm body: scripts/gen_conv256v4.py) against conv_halo.hip
+    on the same inputs: same products, same chunk-major fp32 order, same rounding points (GroupNorm-apply -> bf16 -> SiLU -> bf16 on the way
+    into LDS; bf16(acc + bias) + residual on the way out) -- bit-identical outputs; the GroupNorm partials are sums in another order
+    (1e-6); and against the oracle's GroupNorm + SiLU + conv."""
+    from diffusionkit_amd import ops
+    G, eps = 32, 1e-5
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = bf16r(randn(B, Hs, Ws, C, seed=180, scale=1.5) + 0.3)
+    gamma, beta = bf16r(1 + randn(C, seed=181, scale=0.1)), randn(C, seed=182, scale=0.1)
+    w = randn(O, 3, 3, C, seed=183, scale=0.05)
+    b = randn(O, seed=184, scale=0.1)
+    r = randn(B, H, W, O, seed=185) if res else None
+    P = Prec(BF)
+    act = ov.silu(ov.group_norm_nhwc(x, gamma, beta, G, eps, P), P) if gn else x
+    ref = ov.conv2d_nhwc(ov.upsample_nearest(act) if ups else act, w, b, Prec())
+    if res:
+        ref = ref + r
+    xd = g(x, dev)
+    tab = ops.groupnorm_table(xd, g(gamma, dev), g(beta, dev), G, eps) if gn else None
+    sg = 0 if ups else G
+    outs = {}
+    for mode in (0, 2):
+        try:
+            ops.tune("conv_v4", mode)
+            outs[mode] = ops.conv3x3_gn(xd, g(w, dev).reshape(O, -1), g(b, dev), gn_table=tab, silu=True, res=g(r, dev) if res else None, stats_groups=sg,
+                                        upsample=ups)
+        finally:
+            ops.tune("conv_v4", 1)
+    y0, y1 = (outs[0][0], outs[2][0]) if sg else (outs[0], outs[2])
+    assert rel_l2(ref, y1.float()) < TOL_SINGLE_OP
+    assert torch.equal(y0, y1)
+    if sg:
+        assert rel_l2(outs[0][1].double().cpu(), outs[2][1].double().cpu()) < 1e-6
+
+
 def test_conv3x3_halo_upsample(dev):
     """the upsampling conv (vae.py:20-25,146) on the halo kernel: the nearest-x2 view folded into the halo addressing, no norm"""
     from diffusionkit_amd import ops
