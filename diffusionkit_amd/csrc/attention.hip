@@ -16,7 +16,8 @@
 // of the lean kernel, which is bound by VALU issue, profiles/r04_sd3_pmc.md).
 #include "dk_kernels.h"
 
-extern int g_dk_attn_mode;  // engine.hip; dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 9 = dk_attn4 (8 waves, D = 128 only)
+extern int g_dk_attn_mode;  // engine.hip; dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 9 = dk_attn4 (8 waves, D = 128 only);
+                            // 10 = dk_attn5 (one wave per SIMD, asm tile loop; D = 128, S % 128 == 0: other shapes fall back to 9)
 
 // lab only: trace buffer of attention4.hip's DK4_TRACE builds for the launches this host thread enqueues (scripts/attn_trace.py)
 static thread_local void* g_attn_ws = nullptr;
@@ -32,7 +33,8 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   // automatic choice (kernel lab, profiles/archive/r01_attention_lab.md, r02_attn_bench.log, r03_attention_phase_alternating.md): D = 128 on
   // long sequences: the phase-alternating kernel; otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF against 773 / 823 for the
   // pipelined forms).  A score bias (text encoders) is only implemented by the lean kernel
-  const int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 9 : 4) : g_dk_attn_mode;
+  int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 2048) ? 10 : 4) : g_dk_attn_mode;
+  if (mode == 10 && !dk_attention5_eligible(p)) mode = 9;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   int rc = 0;
   switch (mode) {
@@ -40,13 +42,14 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
     case 9:  // phase-alternating kernel (attention4.hip); D = 128 only
       rc = p.D == 128 ? dk_launch_attention4(p, stream) : dk_launch_attention2(p, 4, stream);
       break;
-    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 9: phase-alternating kernel)");
+    case 10: rc = dk_launch_attention5(p, stream); break;  // one wave per SIMD (attention5.hip)
+    default: DK_REQUIRE(false, "unknown attention variant (4: lean kernel, 9: phase-alternating kernel, 10: one-wave-per-SIMD kernel)");
   }
   dk_prof_end(stream);
   if (rc) return rc;
   DK_CHECK_HIP(hipGetLastError());
-  if (p.O8 != nullptr && !(mode == 9 && p.D == 128)) {
-    // only the phase-alternating kernel writes the MX-fp8 copy itself: quantise the bf16 output behind the others
+  if (p.O8 != nullptr && !((mode == 9 || mode == 10) && p.D == 128)) {
+    // only the D = 128 kernels write the MX-fp8 copy themselves: quantise the bf16 output behind the others
     Mx8Out o8{p.O8, p.O8_scales, p.o8_ld, p.o8_nblk, 0, p.B * p.S, 0, 0};
     return dk_launch_quantize_mx8(p.O, p.ldo, p.B * p.S, 0, p.B * p.S, p.H * p.D, o8, stream);
   }

@@ -1,0 +1,289 @@
+"""Instruction-level emulator for the instruction list of scripts/gen_attn5.py: 4 waves x 64 lanes, unified VGPR / AGPR files, LDS, the two
+counters.  Every LDS-DMA piece lands, and every LDS read delivers, as LATE as the program's waits allow (or at issue); waves run in both orders
+between barriers.  The result (O^T accumulators / row sums) is compared with an fp64 softmax(scale Q K^T) V on the same bf16 inputs.
+
+ds_read_b64_tr_b16 as modelled here: within each group of 16 lanes, lane i supplies the address of 4 consecutive bf16 -- row i >> 2 of a
+4 x 16 block, columns 4 (i & 3) .. + 3 -- and lane j receives column j of the block (rows 0 .. 3)."""
+import numpy as np
+
+from gen_gemm256v4 import bf16_round, bf16_to_f32
+import gen_attn5 as G
+
+lane = np.arange(64)
+l31, hi = lane & 31, lane >> 5
+
+
+def f32(u):
+    return np.asarray(u, np.uint32).view(np.float32)
+
+
+def u32(f):
+    return np.asarray(f, np.float32).view(np.uint32)
+
+
+class W:
+    def __init__(self, wid):
+        self.wid = wid
+        self.R = {"v": np.zeros((256, 64), np.uint32), "a": np.zeros((256, 64), np.uint32)}
+        self.S = {}
+        self.m0 = 0
+        self.scc = 0
+        self.vcc = np.zeros(64, bool)
+        self.pc = 0
+        self.vm, self.lgkm = [], []
+
+
+def frag(regs4):
+    """4 registers x 64 lanes -> [32 rows (l31)][16 k] bf16 values as f32: lane (l31, hi) holds k = 8 hi + 2 r + {0, 1}"""
+    out = np.zeros((32, 16), np.float32)
+    for r in range(4):
+        for h in range(2):
+            vals = bf16_to_f32((regs4[r] >> (16 * h)) & 0xFFFF)
+            out[l31, 8 * hi + 2 * r + h] = vals
+    return out
+
+
+def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
+    rng = np.random.default_rng(seed)
+    S, D, ld = nt * 64, 128, 384
+    scale = 1.0 / np.sqrt(D)
+    c = np.float32(scale * 1.44269504088896340736)
+    thr_c = np.float32(4.0 * 1.44269504088896340736)  # threshold 4 in natural-log units of the scaled scores
+    Q = bf16_to_f32(bf16_round(rng.standard_normal((256, D)).astype(np.float32)))
+    Kf = bf16_to_f32(bf16_round(rng.standard_normal((S, D)).astype(np.float32)))
+    Vf = bf16_to_f32(bf16_round(rng.standard_normal((S, D)).astype(np.float32)))
+    if spike:  # rows whose maximum jumps late: the deferred rescale must fire in the middle of the sequence
+        Kf[S - 100] = Q[5] * 3
+        Kf[200] = Q[70] * 2
+        Kf[S - 1] = Q[255] * 4
+    Kg = np.zeros((S, ld), np.float32)
+    Vg = np.zeros((S, ld), np.float32)
+    Kg[:, :D], Vg[:, :D] = Kf, Vf
+    gl = {"K": np.frombuffer(bf16_round(Kg).astype(np.uint16).tobytes(), np.uint8), "V": np.frombuffer(bf16_round(Vg).astype(np.uint16).tobytes(), np.uint8)}
+    rb = ld * 2
+    lds = np.zeros(64 * 1024, np.uint8)
+    labels = {ins.name: i for i, ins in enumerate(P) if ins.op == "label"}
+    waves = []
+    for w in range(4):
+        wv = W(w)
+        V = wv.R["v"]
+        Qb = bf16_round(Q).astype(np.uint32)
+        for qb in range(2):
+            for kk in range(8):
+                for r in range(4):
+                    row = w * 64 + qb * 32 + l31
+                    col = kk * 16 + hi * 8 + 2 * r
+                    V[128 + (qb * 8 + kk) * 4 + r] = Qb[row, col] | (Qb[row, col + 1] << 16)
+        kr = l31 * 256 + ((hi ^ (l31 & 15)) << 4)
+        for kk in range(8):
+            V[G.KADDR + kk] = kr ^ (kk << 5)
+        x16, p16 = (lane >> 4) & 1, lane & 15
+        for par in range(2):
+            V[G.VADDR + par] = x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8
+        for i in range(4):
+            pi = 4 * w + i
+            row = 4 * pi + (lane >> 4)
+            chunk = (lane & 15) ^ (row & 15)
+            V[G.DK + i] = row * rb + chunk * 16
+            dg, hf = pi >> 1, pi & 1
+            rowpos = hf * 32 + (lane >> 1)
+            kl = rowpos ^ (((dg & 1) << 2) | (dg & 3))
+            V[G.DV + i] = kl * rb + (2 * dg + (lane & 1)) * 16
+        wv.S = {"%[tileb]": 64 * rb, "%[scale]": int(u32(np.float32(scale))), "%[ntrip]": (nt - 4) // 2, "%[dbase]": w * 4096}
+        waves.append(wv)
+
+    def land_all(wv, keep):
+        while len(wv.vm) > keep:
+            wv.vm.pop(0)()
+
+    def deliver_all(wv, keep):
+        while len(wv.lgkm) > keep:
+            wv.lgkm.pop(0)()
+
+    def step(wv):
+        V, A, R = wv.R["v"], wv.R["a"], wv.R
+        while wv.pc < len(P):
+            ins = P[wv.pc]
+            wv.pc += 1
+            op = ins.op
+            if op in ("label", "nop"):
+                continue
+            if op == "barrier":
+                return True
+            if op == "mfma32":
+                fa, ra = ins.a
+                fb, rb_ = ins.b
+                fd, rd = ins.d
+                Am = frag(R[fa][ra:ra + 4])   # [32 m][16 k]
+                Bm = frag(R[fb][rb_:rb_ + 4])  # [32 n][16 k]
+                Dm = Am @ Bm.T                # [m][n]
+                for e in range(16):
+                    m = (e & 3) + 8 * (e >> 2) + 4 * hi
+                    val = Dm[m, l31]
+                    if ins.zero:
+                        R[fd][rd + e] = u32(val.astype(np.float32))
+                    else:
+                        R[fd][rd + e] = u32((f32(R[fd][rd + e]) + val).astype(np.float32))
+            elif op == "ds_read_a":
+                addr = V[ins.addr].astype(np.int64) + ins.off
+                data = lds[addr[:, None] + np.arange(16)[None, :]].copy().view(np.uint32).reshape(64, 4)
+
+                def deliver(data=data, dst=ins.dst):
+                    for r in range(4):
+                        wv.R["a"][dst + r] = data[:, r]
+                if late:
+                    wv.lgkm.append(deliver)
+                else:
+                    deliver()
+                    wv.lgkm.append(lambda: None)
+            elif op == "ds_read_tr":
+                addr = V[ins.addr].astype(np.int64) + ins.off
+                raw = lds[addr[:, None] + np.arange(8)[None, :]].copy().view(np.uint16).reshape(64, 4)  # lane i: 4 consecutive bf16
+                outv = np.zeros((64, 4), np.uint16)
+                for g in range(4):
+                    blk = np.zeros((4, 16), np.uint16)
+                    for i in range(16):
+                        blk[i >> 2, 4 * (i & 3):4 * (i & 3) + 4] = raw[16 * g + i]
+                    for jn in range(16):
+                        outv[16 * g + jn] = blk[:, jn]
+                data = outv.astype(np.uint32)
+                w0, w1 = data[:, 0] | (data[:, 1] << 16), data[:, 2] | (data[:, 3] << 16)
+
+                def deliver(w0=w0, w1=w1, dst=ins.dst):
+                    wv.R["v"][dst], wv.R["v"][dst + 1] = w0, w1
+                if late:
+                    wv.lgkm.append(deliver)
+                else:
+                    deliver()
+                    wv.lgkm.append(lambda: None)
+            elif op == "dma":
+                src = V[ins.vo].astype(np.int64) + wv.S[ins.soff]
+                dst = wv.m0 + lane * 16
+                sidx, didx = src[:, None] + np.arange(16)[None, :], dst[:, None] + np.arange(16)[None, :]
+                g = gl[ins.opnd]
+
+                def land(sidx=sidx, didx=didx, g=g):
+                    lds[didx] = g[sidx]
+                if late:
+                    wv.vm.append(land)
+                else:
+                    land()
+                    wv.vm.append(lambda: None)
+            elif op == "wait":
+                if ins.vm is not None:
+                    land_all(wv, ins.vm)
+                if ins.lgkm is not None:
+                    deliver_all(wv, ins.lgkm)
+            elif op == "s_mov":
+                s = ins.src
+                wv.S[ins.dst] = (wv.S[s] if s.startswith("%") else int(s, 0)) & 0xFFFFFFFF
+            elif op == "s_movi":
+                wv.S[ins.dst] = ins.imm
+            elif op == "s_add":
+                v = (wv.S[ins.a] + ins.imm) & 0xFFFFFFFF
+                if ins.dst == "m0":
+                    wv.m0 = v
+                else:
+                    wv.S[ins.dst] = v
+            elif op == "s_add_s":
+                wv.S[ins.dst] = (wv.S[ins.a] + wv.S[ins.b]) & 0xFFFFFFFF
+            elif op == "s_sub":
+                wv.S[ins.dst] = (wv.S[ins.a] - ins.imm) & 0xFFFFFFFF
+            elif op == "s_cmp_gt":
+                wv.scc = int(wv.S[ins.a] > ins.imm)
+            elif op == "s_cmp_lg":
+                wv.scc = int(wv.S[ins.a] != ins.imm)
+            elif op == "cbranch_scc1":
+                if wv.scc:
+                    wv.pc = labels[ins.target]
+            elif op == "cbranch_vccnz":
+                if wv.vcc.any():
+                    wv.pc = labels[ins.target]
+            elif op == "branch":
+                wv.pc = labels[ins.target]
+            elif op == "acc_write":
+                A[ins.dst] = 0
+            elif op == "acc_write_v":
+                A[ins.dst] = V[ins.src]
+            elif op == "acc_read":
+                V[ins.dst] = A[ins.src]
+            elif op == "v_mov_s":
+                V[ins.dst] = np.uint32(wv.S[ins.src])
+            elif op == "v_mul_lit":
+                V[ins.dst] = u32((f32(np.uint32(ins.lit)) * f32(V[ins.src])).astype(np.float32))
+            elif op == "readfirstlane":
+                wv.S[ins.dst] = int(V[ins.src][0])
+            elif op == "v_movi":
+                V[ins.dst] = np.uint32(ins.imm)
+            elif op == "v_mov":
+                V[ins.dst] = V[ins.src]
+            elif op == "v_fma_sc":
+                cc = f32(np.uint32(wv.S[51]))
+                V[ins.dst] = u32((f32(V[ins.a]).astype(np.float64) * np.float64(cc) - f32(V[ins.mc]).astype(np.float64)).astype(np.float32))
+            elif op == "v_exp":
+                with np.errstate(over="ignore", under="ignore"):
+                    V[ins.dst] = u32(np.exp2(f32(V[ins.dst]).astype(np.float64)).astype(np.float32))
+            elif op == "v_add":
+                V[ins.dst] = u32((f32(V[ins.a]) + f32(V[ins.b])).astype(np.float32))
+            elif op == "v_sub":
+                V[ins.dst] = u32((f32(V[ins.a]) - f32(V[ins.b])).astype(np.float32))
+            elif op == "v_mul":
+                V[ins.dst] = u32((f32(V[ins.a]) * f32(V[ins.b])).astype(np.float32))
+            elif op == "v_mul_s":
+                V[ins.dst] = u32((f32(np.uint32(wv.S[ins.s])) * f32(V[ins.b])).astype(np.float32))
+            elif op == "v_max":
+                V[ins.dst] = u32(np.maximum(f32(V[ins.a]), f32(V[ins.b])))
+            elif op == "v_max3":
+                V[ins.dst] = u32(np.maximum(np.maximum(f32(V[ins.a]), f32(V[ins.b])), f32(V[ins.c])))
+            elif op == "permswap":  # lanes 32-63 of a <-> lanes 0-31 of b
+                a, b = V[ins.a].copy(), V[ins.b].copy()
+                V[ins.a][32:], V[ins.b][:32] = b[:32], a[32:]
+            elif op == "v_cmp_lt_s":
+                wv.vcc = f32(np.uint32(wv.S[ins.s])) < f32(V[ins.b])
+            elif op == "cvt_pk":
+                V[ins.dst] = bf16_round(f32(V[ins.lo])) | (bf16_round(f32(V[ins.hi])) << 16)
+            else:
+                raise ValueError(op)
+        return False
+
+    n_bar = 0
+    while True:
+        alive = [step(wv) for wv in (waves if order == 0 else waves[::-1])]
+        if not any(alive):
+            break
+        assert all(alive), "waves disagree on the barrier count"
+        n_bar += 1
+    if raw:
+        return waves, Q, Kf, Vf, scale
+    # ---- reference
+    sc = (Q.astype(np.float64) @ Kf.astype(np.float64).T) * scale
+    pm = np.exp(sc - sc.max(1, keepdims=True))
+    ref = (pm / pm.sum(1, keepdims=True)) @ Vf.astype(np.float64)
+    got = np.zeros((256, D))
+    for w, wv in enumerate(waves):
+        V = wv.R["v"]
+        for qb in range(2):
+            lrow = f32(V[G.L[qb]])
+            ltot = lrow[:32] + lrow[32:]
+            for dt in range(4):
+                for e in range(16):
+                    d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi
+                    o = f32(V[(qb * 4 + dt) * 16 + e])
+                    got[w * 64 + qb * 32 + l31, d] = o / np.concatenate([ltot, ltot])
+    err = np.abs(got - ref).max()
+    ok = bool(err < 2e-2) and bool(np.isfinite(got).all())
+    if verbose or not ok:
+        print(f"nt {nt} late {late} order {order} spike {spike}: max abs err {err:.3e} (|O| max {np.abs(ref).max():.2f}), barriers {n_bar}, {'ok' if ok else 'WRONG'}")
+        if not ok:
+            bad = np.argwhere(np.abs(got - ref) > 2e-2)
+            print("  first bad (q, d):", bad[:6].tolist(), "count", len(bad))
+    return ok
+
+
+def check_all(P, verbose=False):
+    ok = True
+    for nt, spike in ((6, False), (8, True), (10, False)):
+        for late in (True, False):
+            for order in (0, 1):
+                ok &= run(P, nt, late, order, seed=nt, spike=spike, verbose=verbose)
+    return ok

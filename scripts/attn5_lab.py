@@ -1,0 +1,51 @@
+"""attention5 (one wave per SIMD, asm tile loop; dk_tune_set("attn", 10)) against attention4 (8 waves; 9) through ops.attention: outputs against each other
+and against an fp32 torch softmax on a subset of the heads, then us and TFLOP/s of 4 B H S^2 D per launch.  Small shapes first."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from diffusionkit_amd import ops
+
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(0)
+BF = torch.bfloat16
+shapes = [("S=384 H=2", 1, 2, 384), ("S=1024 H=3 B=2", 2, 3, 1024), ("FLUX schnell", 1, 24, 4352), ("FLUX dev", 1, 24, 4608), ("FLUX schnell B=4", 4, 24, 4352)]
+if os.environ.get("SHAPES"):
+    shapes = [shapes[int(i)] for i in os.environ["SHAPES"].split(",")]
+D = 128
+ok = True
+for name, B, H, S in shapes:
+    qkv = torch.randn(B, S, 3 * H * D, device=dev, generator=g).to(BF)
+    if os.environ.get("SPIKE"):
+        qkv[:, S - 100, H * D:H * D + D] = qkv[:, 5, :D] * 3  # a key that lifts row 5's maximum late in the sequence
+    outs, times = {}, {}
+    for mode in (9, 10):
+        ops.tune("attn", mode)
+        outs[mode] = ops.attention(qkv, H, D)
+        torch.cuda.synchronize()
+        best = 1e9
+        for rnd in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.attention(qkv, H, D)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 10)
+        times[mode] = best
+    ops.tune("attn", -1)
+    hs = min(H, 2)
+    q, k, v = [qkv[:, :, i * H * D:i * H * D + hs * D].float().reshape(B, S, hs, D).permute(0, 2, 1, 3) for i in range(3)]
+    ref = torch.softmax(q @ k.transpose(-1, -2) / D ** 0.5, -1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B, S, hs * D)
+    e9 = float((outs[9][:, :, :hs * D].float() - ref).abs().max())
+    e10 = float((outs[10][:, :, :hs * D].float() - ref).abs().max())
+    d = float((outs[9].float() - outs[10].float()).abs().max())
+    good = e10 < max(2.5 * e9, 2e-2) and bool(torch.isfinite(outs[10].float()).all())
+    ok &= good
+    fl = 4.0 * B * H * S * S * D
+    print(f"{name}: max err vs fp32 -- attn4 {e9:.2e}, attn5 {e10:.2e}; attn4 vs attn5 {d:.2e} {'ok' if good else 'WRONG'} | attn4 {times[9] * 1e3:7.1f} us {fl / times[9] / 1e9:6.0f} TF"
+          f" | attn5 {times[10] * 1e3:7.1f} us {fl / times[10] / 1e9:6.0f} TF", flush=True)
+print("ALL OK" if ok else "MISMATCH", flush=True)
