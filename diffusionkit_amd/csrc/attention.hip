@@ -17,7 +17,7 @@
 #include "dk_kernels.h"
 
 extern int g_dk_attn_mode;  // engine.hip; dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 9 = dk_attn4 (8 waves, D = 128 only);
-                            // 10 = dk_attn5 (one wave per SIMD, asm tile loop; D = 128, S % 128 == 0: other shapes fall back to 9)
+                            // 10 = dk_attn5 (one wave per SIMD, asm tile loop; D = 128, S % 256 == 0: other shapes fall back to 9)
 
 // lab only: trace buffer of attention4.hip's DK4_TRACE builds for the launches this host thread enqueues (scripts/attn_trace.py)
 static thread_local void* g_attn_ws = nullptr;

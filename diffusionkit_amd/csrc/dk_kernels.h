@@ -172,7 +172,7 @@ extern int g_dk_attn_mode;
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 int dk_launch_attention4(const AttnParams& p, hipStream_t stream);             // attention4.hip (the waves of a SIMD in opposite phases; D = 128, no score bias)
-bool dk_attention5_eligible(const AttnParams& p);                              // attention5.hip (one wave per SIMD, asm tile loop; D = 128, S % 128 == 0, no score bias)
+bool dk_attention5_eligible(const AttnParams& p);                              // attention5.hip (one wave per SIMD, asm tile loop; D = 128, S % 256 == 0, no score bias)
 int dk_launch_attention5(const AttnParams& p, hipStream_t stream);
 
 // ---- single-head D = 512 attention of the VAE's mid block (attention512.hip) -------------------------------

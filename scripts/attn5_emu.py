@@ -61,7 +61,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
     Kg[:, :D], Vg[:, :D] = Kf, Vf
     gl = {"K": np.frombuffer(bf16_round(Kg).astype(np.uint16).tobytes(), np.uint8), "V": np.frombuffer(bf16_round(Vg).astype(np.uint16).tobytes(), np.uint8)}
     rb = ld * 2
-    lds = np.zeros(64 * 1024, np.uint8)
+    lds = np.zeros(128 * 1024, np.uint8)
     labels = {ins.name: i for i, ins in enumerate(P) if ins.op == "label"}
     waves = []
     for w in range(4):
@@ -79,7 +79,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
             V[G.KADDR + kk] = kr ^ (kk << 5)
         x16, p16 = (lane >> 4) & 1, lane & 15
         for par in range(2):
-            V[G.VADDR + par] = x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8
+            V[G.VADDR + par] = G.V_LDS + x16 * 2048 + ((4 * (hi ^ x16) + (p16 >> 2)) ^ (2 * par + x16)) * 32 + (p16 & 3) * 8
         for i in range(4):
             pi = 4 * w + i
             row = 4 * pi + (lane >> 4)
@@ -89,7 +89,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
             rowpos = hf * 32 + (lane >> 1)
             kl = rowpos ^ (((dg & 1) << 2) | (dg & 3))
             V[G.DV + i] = kl * rb + (2 * dg + (lane & 1)) * 16
-        wv.S = {"%[tileb]": 64 * rb, "%[scale]": int(u32(np.float32(scale))), "%[ntrip]": (nt - 4) // 2, "%[dbase]": w * 4096}
+        wv.S = {"%[koff]": 4 * 64 * rb, "%[voff]": 3 * 64 * rb, "%[tileb]": 64 * rb, "%[scale]": int(u32(np.float32(scale))), "%[ntrip]": (nt - 8) // 4, "%[dbase]": w * 4096}
         waves.append(wv)
 
     def land_all(wv, keep):
@@ -106,7 +106,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
             ins = P[wv.pc]
             wv.pc += 1
             op = ins.op
-            if op in ("label", "nop"):
+            if op in ("label", "nop", "split"):
                 continue
             if op == "barrier":
                 return True
@@ -191,6 +191,18 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
                 wv.S[ins.dst] = (wv.S[ins.a] - ins.imm) & 0xFFFFFFFF
             elif op == "s_cmp_gt":
                 wv.scc = int(wv.S[ins.a] > ins.imm)
+            elif op == "s_cmp_lg64":
+                wv.scc = int((wv.S[ins.a] | wv.S[ins.a + 1]) != 0)
+            elif op == "s_mov64":
+                wv.S[ins.dst], wv.S[ins.dst + 1] = 0, 0
+            elif op == "s_or_vcc":
+                m = 0
+                for b in np.nonzero(wv.vcc)[0]:
+                    m |= 1 << int(b)
+                wv.S[ins.dst] |= m & 0xFFFFFFFF
+                wv.S[ins.dst + 1] |= m >> 32
+            elif op == "v_cndmask":
+                V[ins.dst] = np.where(wv.vcc, V[ins.b], V[ins.a])
             elif op == "s_cmp_lg":
                 wv.scc = int(wv.S[ins.a] != ins.imm)
             elif op == "cbranch_scc1":
@@ -282,7 +294,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
 
 def check_all(P, verbose=False):
     ok = True
-    for nt, spike in ((6, False), (8, True), (10, False)):
+    for nt, spike in ((12, False), (16, True), (20, False)):
         for late in (True, False):
             for order in (0, 1):
                 ok &= run(P, nt, late, order, seed=nt, spike=spike, verbose=verbose)

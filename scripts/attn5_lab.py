@@ -11,7 +11,7 @@ from diffusionkit_amd import ops
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 BF = torch.bfloat16
-shapes = [("S=384 H=2", 1, 2, 384), ("S=1024 H=3 B=2", 2, 3, 1024), ("FLUX schnell", 1, 24, 4352), ("FLUX dev", 1, 24, 4608), ("FLUX schnell B=4", 4, 24, 4352)]
+shapes = [("S=768 H=2", 1, 2, 768), ("S=1024 H=3 B=2", 2, 3, 1024), ("FLUX schnell", 1, 24, 4352), ("FLUX dev", 1, 24, 4608), ("FLUX schnell B=4", 4, 24, 4352)]
 if os.environ.get("SHAPES"):
     shapes = [shapes[int(i)] for i in os.environ["SHAPES"].split(",")]
 D = 128

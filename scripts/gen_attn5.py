@@ -25,7 +25,7 @@ that P.V is complete (a rare, out-of-line block).
 v[224:225] mc = running max * c   v[226:227] l   v[228:231] psum[parity][qb]   v[232:233] pend   v[234:237] temporaries
 v[238:245] K read addresses per kk   v[246:247] V read offsets (dt parity)   v[248:251] K piece offsets   v[252:255] V piece offsets
 s[40:43] K resource  s[44:47] V resource  s48 K tile offset  s49 V tile offset  s50 tile bytes  s51 c = scale*log2(e)  s52 threshold*c
-s53 loop counter  s54 rescale flag  s55 DMA base of this wave (wave*4096)
+s53 loop counter  s55 DMA base of this wave (wave*4096)  s[56:57] rows whose offset moved (rescale pending)
 """
 import os
 import sys
@@ -43,8 +43,13 @@ PS = [[228, 229], [230, 231]]
 TMP = [234, 235, 236, 237]
 KADDR, VADDR, DK, DV = 238, 246, 248, 252
 A_O, A_Q, A_K = 0, 128, 192
-K_LDS, V_LDS, TILE = 0, 32768, 16384
+K_LDS, V_LDS, TILE, DEPTH = 0, 65536, 16384, 4  # four-slot rings: a piece has 2.5 - 3 tiles to land
 VM_OPS = ("dma",)
+# lab only (scripts/build_attn5_abl.sh): bit mask of what the tile loop leaves out -- 1 the exponentials (fma, exp, add), 2 the row maxima + the rescale
+# test, 4 the bf16 packs, 8 the DMA pieces of the loop, 16 the V reads, 32 the K reads, 64 the MFMAs.  Results are wrong; the timings say what each costs.
+ABL = int(os.environ.get("A5_ABL", "0"))
+# lab only: schedule options, comma separated -- exp=grouped|pipelined|simple, merge=concat|rr, expop=mul (the exponentials become multiplies: wrong results)
+OPT = dict(kv.split("=") for kv in os.environ.get("A5_OPT", "").split(",") if kv)
 
 
 def sblk(t, qb, half):
@@ -83,7 +88,7 @@ def v_reads(slot):
     for n in range(4):
         for dt in range(4):
             d = VFR + (dt * 4 + n) * 4
-            imm = V_LDS + slot * TILE + dt * 4096 + (32 * (n >> 1) + 16 * (n & 1)) * 32
+            imm = slot * TILE + dt * 4096 + (32 * (n >> 1) + 16 * (n & 1)) * 32  # (V_LDS sits in the address registers: the offset field has 16 bits)
             for h in range(2):
                 out.append(I("ds_read_tr", f"ds_read_b64_tr_b16 v[{d + 2 * h}:{d + 2 * h + 1}], v{VADDR + (dt & 1)} offset:{imm + 256 * h}",
                              dst=d + 2 * h, addr=VADDR + (dt & 1), off=imm + 256 * h))
@@ -95,40 +100,56 @@ def dma_pieces(opnd, slot, tag):
     out = []
     base = (K_LDS if opnd == "K" else V_LDS) + slot * TILE
     for i in range(4):
-        out.append([I("s_add", f"s_add_u32 m0, s55, {base + i * 1024}", dst="m0", a=55, imm=base + i * 1024), I("nop", "s_nop 0"),
+        out.append([I("s_add", f"s_add_u32 m0, s55, {base + i * 1024}", dst="m0", a=55, imm=base + i * 1024),
                     I("dma", f"buffer_load_dwordx4 v{(DK if opnd == 'K' else DV) + i}, s[{40 if opnd == 'K' else 44}:{43 if opnd == 'K' else 47}], s{48 if opnd == 'K' else 49} offen lds",
                       opnd=opnd, vo=(DK if opnd == "K" else DV) + i, soff=48 if opnd == "K" else 49, tag=tag)])
     return out
 
 
 def exp_stream(t, halves):
-    """p = exp2(s * c - mc) in place, row sums into psum[t & 1][qb]; per (half, qb) 16 scores: fma, exp, add"""
+    """p = exp2(s * c - mc) in place and the row sums: four scores in lockstep -- (e, e + 1) of both query blocks: four fma, four exp, four adds
+    into four different sums (psum and a second partial sum per block, TMP[1] / TMP[3], folded in behind the second score half).
+    Lab orders (A5_OPT exp=...): pipelined (fma of score i + 4, exp of i + 2, add of i), simple (one score at a time)."""
     out = []
+    order = OPT.get("exp", "grouped")
+    expi = (lambda r: I("v_mul", f"v_mul_f32 v{r}, v{r}, v{r}", dst=r, a=r, b=r)) if OPT.get("expop") == "mul" else (lambda r: I("v_exp", f"v_exp_f32 v{r}, v{r}", dst=r))
+
+    def fma(qb, r):
+        return I("v_fma_sc", f"v_fma_f32 v{r}, v{r}, s51, -v{MC[qb]}", dst=r, a=r, mc=MC[qb])
+
+    def add(half, k, qb, odd, r):
+        d = TMP[2 * qb + 1] if odd else PS[t & 1][qb]
+        if half == 0 and k < 4:
+            return I("v_mov", f"v_mov_b32 v{d}, v{r}", dst=d, src=r)
+        return I("v_add", f"v_add_f32 v{d}, v{d}, v{r}", dst=d, a=d, b=r)
     for half in halves:
-        for qb in range(2):
-            s0 = sblk(t, qb, half)
-            ps = PS[t & 1][qb]
-            for e in range(16):
-                r = s0 + e
-                out.append(I("v_fma_sc", f"v_fma_f32 v{r}, v{r}, s51, -v{MC[qb]}", dst=r, a=r, mc=MC[qb]))
-                out.append(I("v_exp", f"v_exp_f32 v{r}, v{r}", dst=r))
-                if half == 0 and e == 1:
-                    out.append(I("v_add", f"v_add_f32 v{ps}, v{r - 1}, v{r}", dst=ps, a=r - 1, b=r))
-                elif not (half == 0 and e == 0):
-                    out.append(I("v_add", f"v_add_f32 v{ps}, v{ps}, v{r}", dst=ps, a=ps, b=r))
-    # (an exponential's result needs a wait state before its use: the add of score e is moved behind the fma of score e + 1)
-    fixed = []
-    i = 0
-    while i < len(out):
-        if out[i].op == "v_add" and i + 1 < len(out) and out[i + 1].op == "v_fma_sc":
-            fixed.extend([out[i + 1], out[i]])
-            i += 2
+        el = [(qb, odd, sblk(t, qb, half) + e + odd) for e in range(0, 16, 2) for qb in range(2) for odd in range(2)]
+        n = len(el)
+        if order == "pipelined":
+            for k in range(-4, n):
+                if 0 <= k + 4 < n:
+                    out.append(fma(el[k + 4][0], el[k + 4][2]))
+                if 0 <= k + 2 < n:
+                    out.append(expi(el[k + 2][2]))
+                if 0 <= k < n:
+                    out.append(add(half, k, *el[k]))
+        elif order == "simple":
+            for k in range(n):
+                out.append(fma(el[k][0], el[k][2]))
+                out.append(expi(el[k][2]))
+                if k > 0:
+                    out.append(add(half, k - 1, *el[k - 1]))
+            out.append(I("nop", "s_nop 0"))
+            out.append(add(half, n - 1, *el[n - 1]))
         else:
-            fixed.append(out[i])
-            i += 1
-    if len(fixed) >= 2 and fixed[-1].op == "v_add" and fixed[-2].op == "v_exp":
-        fixed.insert(-1, I("nop", "s_nop 0"))
-    return fixed
+            for g0 in range(0, n, 4):
+                out.extend(fma(qb, r) for qb, odd, r in el[g0:g0 + 4])
+                out.extend(expi(r) for qb, odd, r in el[g0:g0 + 4])
+                out.extend(add(half, g0 + i, *el[g0 + i]) for i in range(4))
+        if half == 1:
+            for qb in range(2):
+                out.append(I("v_add", f"v_add_f32 v{PS[t & 1][qb]}, v{PS[t & 1][qb]}, v{TMP[2 * qb + 1]}", dst=PS[t & 1][qb], a=PS[t & 1][qb], b=TMP[2 * qb + 1]))
+    return out
 
 
 def pack_stream(t):
@@ -144,44 +165,47 @@ def pack_stream(t):
 
 
 def max_stream(t, label):
-    """row maxima of S(t) (lane-local over its 32 keys, then across the two halves), the deferred-rescale test; the rare path is out of line"""
+    """row maxima of S(t) (lane-local over its 32 keys, then across the two halves) and the deferred-rescale test; the rare path is out of line.
+    Eight independent chains (four per query block, eight scores each) run in lockstep; their temporaries are registers of the OTHER score set,
+    dead between the packs of tile t - 1 and the scores of tile t + 1.  Returns the 36 chain instructions, then four units that stay together."""
     out = []
     chains = []
     for qb in range(2):
-        a, b = sblk(t, qb, 0), sblk(t, qb, 1)
-        m = TMP[2 * qb]
-        ch = [I("v_max3", f"v_max3_f32 v{m}, v{a}, v{a + 1}, v{b}", dst=m, a=a, b=a + 1, c=b)]
-        for e in range(1, 16):
-            x, y = (a + e + 1, b + e) if e < 15 else (b + 15, b + 15)
-            ch.append(I("v_max3", f"v_max3_f32 v{m}, v{m}, v{x}, v{y}", dst=m, a=m, b=x, c=y))
-        chains.append(ch)
-    for x, y in zip(*chains):  # the two blocks' dependent chains alternate
-        out.extend([x, y])
-    for qb in range(2):  # (units: what must stay together in one MFMA gap -- a branch and its return label above all)
+        x = [sblk(t, qb, 0) + e for e in range(16)] + [sblk(t, qb, 1) + e for e in range(16)]
+        for c in range(4):
+            T = SSET[(t & 1) ^ 1] + qb * 4 + c
+            v = x[c::4]  # 8 scores
+            chains.append([I("v_max3", f"v_max3_f32 v{T}, v{v[0]}, v{v[1]}, v{v[2]}", dst=T, a=v[0], b=v[1], c=v[2]),
+                           I("v_max3", f"v_max3_f32 v{T}, v{T}, v{v[3]}, v{v[4]}", dst=T, a=T, b=v[3], c=v[4]),
+                           I("v_max3", f"v_max3_f32 v{T}, v{T}, v{v[5]}, v{v[6]}", dst=T, a=T, b=v[5], c=v[6]),
+                           I("v_max", f"v_max_f32 v{T}, v{T}, v{v[7]}", dst=T, a=T, b=v[7])])
+    for step in zip(*chains):
+        out.extend(step)
+    for k in range(2):
+        for qb in range(2):
+            T, m = SSET[(t & 1) ^ 1] + qb * 4, TMP[2 * qb]
+            if k == 0:
+                out.append(I("v_max3", f"v_max3_f32 v{m}, v{T}, v{T + 1}, v{T + 2}", dst=m, a=T, b=T + 1, c=T + 2))
+            else:
+                out.append(I("v_max", f"v_max_f32 v{m}, v{m}, v{T + 3}", dst=m, a=m, b=T + 3))
+    units = []
+    for qb in range(2):  # (units: what stays together in one MFMA gap)
         m, u = TMP[2 * qb], TMP[2 * qb + 1]
-        out.append([I("v_mov", f"v_mov_b32 v{u}, v{m}", dst=u, src=m), I("nop", "s_nop 1"), I("permswap", f"v_permlane32_swap_b32 v{m}, v{u}", a=m, b=u),
-                    I("v_max", f"v_max_f32 v{m}, v{m}, v{u}", dst=m, a=m, b=u)])
-        out.append([I("v_fma_sc", f"v_fma_f32 v{u}, v{m}, s51, -v{MC[qb]}", dst=u, a=m, mc=MC[qb]), I("v_cmp_lt_s", f"v_cmp_lt_f32 vcc, s52, v{u}", s=52, b=u),
-                    I("cbranch_vccnz", f"s_cbranch_vccnz {label + qb}f", target=f"RARE{label + qb}"), I("label", f"{label + 2 + qb}:", name=f"BACK{label + qb}")])
-    return out
-
-
-def rare_blocks(label):
-    """a row's maximum grew by more than the threshold: new offset, the factor for everything still at the old scale is recorded in pend"""
-    out = []
+        units.append([I("v_mov", f"v_mov_b32 v{u}, v{m}", dst=u, src=m), I("nop", "s_nop 1"), I("permswap", f"v_permlane32_swap_b32 v{m}, v{u}", a=m, b=u),
+                      I("v_max", f"v_max_f32 v{m}, v{m}, v{u}", dst=m, a=m, b=u)])
+    # The deferred rescale WITHOUT a branch (a branch on VCC costs ~270 cycles here: it waits for the vector and matrix pipes; measured with the
+    # lab masks 512 / 256 of this script): per row, if the new maximum exceeds the offset by more than the threshold the offset moves to it and
+    # the factor exp2(old - new) is recorded in pend; otherwise new = old and the factor is exactly 1.  s[56:57] collects the rows that moved.
     for qb in range(2):
-        m, u = TMP[2 * qb], TMP[2 * qb + 1]
-        out.append(I("label", f"{label + qb}:", name=f"RARE{label + qb}"))
-        out.append(I("v_mul_s", f"v_mul_f32 v{m}, s51, v{m}", dst=m, s=51, b=m))
-        out.append(I("v_max", f"v_max_f32 v{m}, v{m}, v{MC[qb]}", dst=m, a=m, b=MC[qb]))
-        out.append(I("v_sub", f"v_sub_f32 v{u}, v{MC[qb]}, v{m}", dst=u, a=MC[qb], b=m))
-        out.append(I("v_exp", f"v_exp_f32 v{u}, v{u}", dst=u))
-        out.append(I("v_mov", f"v_mov_b32 v{MC[qb]}, v{m}", dst=MC[qb], src=m))
-        out.append(I("nop", "s_nop 0"))
-        out.append(I("v_mul", f"v_mul_f32 v{PEND[qb]}, v{PEND[qb]}, v{u}", dst=PEND[qb], a=PEND[qb], b=u))
-        out.append(I("s_movi", "s_mov_b32 s54, 1", dst=54, imm=1))
-        out.append(I("branch", f"s_branch {label + 2 + qb}b", target=f"BACK{label + qb}"))
-    return out
+        m, u, mc = TMP[2 * qb], TMP[2 * qb + 1], MC[qb]
+        units.append([I("v_fma_sc", f"v_fma_f32 v{u}, v{m}, s51, -v{mc}", dst=u, a=m, mc=mc), I("v_mul_s", f"v_mul_f32 v{m}, s51, v{m}", dst=m, s=51, b=m),
+                      I("v_cmp_lt_s", f"v_cmp_lt_f32 vcc, s52, v{u}", s=52, b=u), I("s_or_vcc", "s_or_b64 s[56:57], s[56:57], vcc", dst=56),
+                      I("v_cndmask", f"v_cndmask_b32 v{m}, v{mc}, v{m}, vcc", dst=m, a=mc, b=m)])
+        units.append([I("v_sub", f"v_sub_f32 v{u}, v{mc}, v{m}", dst=u, a=mc, b=m), I("v_mov", f"v_mov_b32 v{mc}, v{m}", dst=mc, src=m),
+                      I("v_exp", f"v_exp_f32 v{u}, v{u}", dst=u)])
+    for qb in range(2):
+        units.append([I("v_mul", f"v_mul_f32 v{PEND[qb]}, v{PEND[qb]}, v{TMP[2 * qb + 1]}", dst=PEND[qb], a=PEND[qb], b=TMP[2 * qb + 1])])
+    return out + units
 
 
 def rescale_block(label):
@@ -191,24 +215,60 @@ def rescale_block(label):
         out.append(I("v_mul", f"v_mul_f32 v{L[qb]}, v{L[qb]}, v{PEND[qb]}", dst=L[qb], a=L[qb], b=PEND[qb]))
         for r in range(64):
             a = A_O + qb * 64 + r
-            t = TMP[r & 3]
+            t = PF + (r & 3)  # (the P fragment registers are dead here; TMP carries partial row sums across the phase boundary)
             out.append(I("acc_read", f"v_accvgpr_read_b32 v{t}, a{a}", dst=t, src=a))
             out.append(I("nop", "s_nop 0"))
             out.append(I("v_mul", f"v_mul_f32 v{t}, v{t}, v{PEND[qb]}", dst=t, a=t, b=PEND[qb]))
             out.append(I("nop", "s_nop 0"))
             out.append(I("acc_write_v", f"v_accvgpr_write_b32 a{a}, v{t}", dst=a, src=t))
         out.append(I("v_movi", f"v_mov_b32 v{PEND[qb]}, 1.0", dst=PEND[qb], imm=0x3f800000))
-    out.append(I("s_movi", "s_mov_b32 s54, 0", dst=54, imm=0))
+    out.append(I("s_mov64", "s_mov_b64 s[56:57], 0", dst=56, imm=0))
     out.append(I("branch", f"s_branch {label + 1}b", target=f"RESCBACK{label}"))
     return out
 
 
-def spread(gaps, items, lo, hi, cap=None):
-    """put `items` (instructions or lists that stay together) into gaps lo .. hi - 1, evenly, in order"""
-    n = len(items)
-    for s, it in enumerate(items):
-        g = lo + (s * (hi - lo)) // max(n, 1)
-        gaps[g].extend(it if isinstance(it, list) else [it])
+class Gaps:
+    """the 32 MFMA gaps of a phase (+ one behind the last MFMA): every stream is spread over its window on its own; inside a gap the streams
+    are merged round-robin, so that the exponentials of one stream sit between instructions of the others"""
+
+    def __init__(self):
+        self.streams = []  # per stream: 33 lists of units
+
+    def load(self, g):
+        return sum(len(u) for st in self.streams for u in st[g])
+
+    def spread(self, items, lo, hi):
+        """put `items` (instructions, or lists that stay together) into gaps lo .. hi - 1 in order: each item goes to the less loaded of the gap
+        at its even-spread position and the next one (never in front of its predecessor)"""
+        st = [[] for _ in range(33)]
+        self.streams.append(st)
+        n, last = len(items), lo
+        for s, it in enumerate(items):
+            ideal = lo + (s * (hi - lo)) // max(n, 1)
+            cand = [g for g in (ideal, ideal + 1) if last <= g < hi] or [max(last, min(ideal, hi - 1))]
+            g = min(cand, key=lambda x: (self.load(x), x))
+            st[g].append(it if isinstance(it, list) else [it])
+            last = g
+        return st
+
+    def put(self, g, unit, front=False):
+        st = [[] for _ in range(33)]
+        st[g].append(unit if isinstance(unit, list) else [unit])
+        if front:
+            self.streams.insert(0, st)
+        else:
+            self.streams.append(st)
+
+    def gap(self, g):
+        out = []
+        qs = [list(st[g]) for st in self.streams if st[g]]
+        if OPT.get("merge", "concat") == "concat":
+            return [ins for q in qs for u in q for ins in u]
+        while qs:
+            for q in qs:
+                out.extend(q.pop(0))
+            qs = [q for q in qs if q]
+        return out
 
 
 def iteration(j, lab, qk=True, pv=True, kread=True, dma_k=True, dma_v=True, mx=True, exp_head=True, landed=True):
@@ -216,76 +276,108 @@ def iteration(j, lab, qk=True, pv=True, kread=True, dma_k=True, dma_v=True, mx=T
     lab: base of this copy's numeric labels (10 per copy)"""
     p = j & 1
     out, tails = [], []
+    if (ABL & 8) and j >= 0:
+        dma_k = dma_v = landed = False
     # ---- phase 1 ----
-    g1 = [[] for _ in range(33)]
+    g1 = Gaps()
     head = []
     if pv:  # the row sums of tile j - 1 are final; a recorded rescale is applied now (P(j - 1) V(j - 1) is complete)
         for qb in range(2):
             head.append(I("v_add", f"v_add_f32 v{L[qb]}, v{L[qb]}, v{PS[p ^ 1][qb]}", dst=L[qb], a=L[qb], b=PS[p ^ 1][qb]))
-        head.append(I("s_cmp_lg", "s_cmp_lg_u32 s54, 0", a=54, imm=0))
-        head.append(I("cbranch_scc1", f"s_cbranch_scc1 {lab + 8}f", target=f"RESC{lab + 8}"))
+        head.append(I("s_cmp_lg64", "s_cmp_lg_u64 s[56:57], 0", a=56))
+        if not (ABL & 2048):
+            head.append(I("cbranch_scc1", f"s_cbranch_scc1 {lab + 8}f", target=f"RESC{lab + 8}"))
         head.append(I("label", f"{lab + 9}:", name=f"RESCBACK{lab + 8}"))
         tails.extend(rescale_block(lab + 8))
+    qk = qk and not (ABL & 64) and not (ABL & 4096)
     mf1 = [mfma_qk(j + 1, qb, half, kk) for kk in range(8) for half in range(2) for qb in range(2)] if qk else []
     if pv:
-        spread(g1, v_reads(p), 0, 22)
-        # exponentials of the second score half of tile j (the first half's ran a phase ago), the packs of P(j): k-steps 0, 1 beside them,
-        # k-steps 2, 3 behind them
+        # V(j) reads; exponentials of the second score half of tile j (the first half's ran a phase ago); the packs of P(j): k-steps 0, 1
+        # beside them, k-steps 2, 3 behind them
         pk = pack_stream(j)
-        spread(g1, exp_stream(j, [1]), 0, 26)
-        spread(g1, pk[:16], 1, 26)
-        spread(g1, pk[16:], 26, 32)
+        if not (ABL & 1):
+            g1.spread(exp_stream(j, [1]), 0, 29)
+        if not (ABL & 16):
+            g1.spread(v_reads(j % DEPTH), 0, 26)
+        if not (ABL & 4):
+            g1.spread(pk[:16], 0, 29)
+            g1.spread(pk[16:], 29, 32)
     for m in range(32):
         if m == 0:
             out.extend(head)
         if qk:
             out.append(mf1[m])
-        out.extend(g1[m])
-    out.extend(g1[32])
-    # ---- middle: K(j + 2) and V(j + 1) have landed (every piece issued a phase ago); all fragment reads of phase 1 are done ----
-    out.append(need(("T", j + 1)) if landed else wait(vm=0))
+        out.extend(g1.gap(m))
+    # ---- middle: K(j + 2) and V(j + 1) have landed (issued three iterations ago); all fragment reads of phase 1 are done ----
+    out.append(need(("T", j - 3)) if landed else wait(vm=0))
     out.append(wait(lgkm=0))
     out.append(BARRIER())
     # ---- phase 2 ----
-    g2 = [[] for _ in range(33)]
-    mf2 = [mfma_pv(qb, dt, n) for n in range(4) for dt in range(4) for qb in range(2)] if pv else []
-    if kread:
-        spread(g2, k_reads(p), 0, 16)
-    if mx:
-        spread(g2, max_stream(j + 1, lab), 3, 13)
-        tails.extend(rare_blocks(lab))
-    if exp_head:
-        spread(g2, exp_stream(j + 1, [0]), 13, 32)
+    g2 = Gaps()
+    pv_m = pv and not (ABL & 64) and not (ABL & 8192)
+    mf2 = [mfma_pv(qb, dt, n) for n in range(4) for dt in range(4) for qb in range(2)] if pv_m else []
+    if exp_head and not (ABL & 1):
+        g2.spread(exp_stream(j + 1, [0]), 14, 32)
+    if mx and not (ABL & 2):  # the eight maximum chains over gaps 1 .. 7, then exchange / test + select / factor / pend of the two blocks
+        ms = max_stream(j + 1, lab)
+        if not (ABL & 128):
+            g2.spread(ms[:36], 1, 8)
+        for k, u in enumerate(ms[36:]):
+            if not (ABL & 256):
+                g2.put(8 + min(k, 5), u)
+    if kread and not (ABL & 32):
+        g2.spread(k_reads((j + 2) % DEPTH), 0, 22)
     pieces = []
     if dma_k:
-        pieces += dma_pieces("K", (j + 3) & 1, ("T", j + 2))
+        pieces += dma_pieces("K", (j + 5) % DEPTH, ("T", j))
     if dma_v:
-        pieces += dma_pieces("V", (j + 2) & 1, ("T", j + 2))
-    spread(g2, pieces, 14, 32)
+        pieces += dma_pieces("V", (j + 4) % DEPTH, ("T", j))
+    for s_, (m0w, piece) in enumerate(pieces):  # the M0 write closes gap g - 1, the piece opens gap g (an SALU write of M0 needs a wait state first)
+        g = 2 + (s_ * 28) // max(len(pieces), 1)
+        g2.put(g - 1, m0w)
+        g2.put(g, piece, front=True)
+    if dma_k:  # the tile offsets move on behind the last piece
+        g2.put(30, I("s_add_s", "s_add_u32 s48, s48, s50", dst=48, a=48, b=50))
+    if dma_v:
+        g2.put(31, I("s_add_s", "s_add_u32 s49, s49, s50", dst=49, a=49, b=50))
     for m in range(32):
-        if pv:
+        if pv_m:
             out.append(mf2[m])
-        out.extend(g2[m])
-    out.extend(g2[32])
-    if dma_k:
-        out.append(I("s_add_s", "s_add_u32 s48, s48, s50", dst=48, a=48, b=50))
-    if dma_v:
-        out.append(I("s_add_s", "s_add_u32 s49, s49, s50", dst=49, a=49, b=50))
+        out.extend(g2.gap(m))
     out.append(wait(lgkm=0))  # K(j + 2) sits in the AGPRs
     return out, tails
 
 
 def program():
-    """nt = S / 64 tiles, even, >= 6.  Prologue (tile -1: scores of tile 0 only), a two-tile loop over j = 0 .. nt - 5, four peeled iterations."""
+    """nt = S / 64 tiles, a multiple of 4, >= 12.  Prologue (K(0..3), V(0..2); iteration -1: the scores of tile 0), a four-tile loop over
+    j = 0 .. nt - 9, eight peeled iterations."""
     P, tails = [], []
-    for d, s in ((48, "0"), (49, "0"), (50, "%[tileb]"), (52, "0x40b8aa3b"), (53, "%[ntrip]"), (54, "0"), (55, "%[dbase]")):  # s52 = 4 * log2(e)
+    # ---- block 1 (its own asm statement, in front of the query loads): the first seven tiles' DMA pieces: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2)
+    # (the order the waits retire them in); the loads of the query rows behind them share their round trip
+    for d, s in ((48, "0"), (49, "0"), (50, "%[tileb]"), (55, "%[dbase]")):
+        P.append(I("s_mov", f"s_mov_b32 s{d}, {s}", dst=d, src=s))
+    pro = []
+
+    def issue(opnd, t, tag):
+        for m0w, piece in dma_pieces(opnd, t % DEPTH, tag):
+            pro.extend([m0w, I("nop", "s_nop 0"), piece])
+        r = 48 if opnd == "K" else 49
+        pro.append(I("s_add_s", f"s_add_u32 s{r}, s{r}, s50", dst=r, a=r, b=50))
+    issue("K", 0, "P0")
+    for t in range(3):
+        issue("K", t + 1, ("T", t - 4))
+        issue("V", t, ("T", t - 4))
+    P.extend(pro)
+    P.append(I("split", None))
+    # ---- block 2
+    for d, s in ((48, "%[koff]"), (49, "%[voff]"), (50, "%[tileb]"), (52, "0x40b8aa3b"), (53, "%[ntrip]"), (55, "%[dbase]"), (56, "0"), (57, "0")):  # s52 = 4 * log2(e)
         P.append(I("s_mov", f"s_mov_b32 s{d}, {s}", dst=d, src=s))
     # c = scale * log2(e) into s51 (a float product has no scalar instruction: through a VGPR)
     P.append(I("v_mov_s", f"v_mov_b32 v{TMP[0]}, %[scale]", dst=TMP[0], src="%[scale]"))
     P.append(I("v_mul_lit", f"v_mul_f32 v{TMP[0]}, 0x3fb8aa3b, v{TMP[0]}", dst=TMP[0], src=TMP[0], lit=0x3fb8aa3b))
     P.append(I("nop", "s_nop 1"))
     P.append(I("readfirstlane", f"v_readfirstlane_b32 s51, v{TMP[0]}", dst=51, src=TMP[0]))
-    # Q fragments arrive in v[128:191] (inputs) -> a[128:191]; accumulators, row sums, offsets
+    # Q fragments arrive in v[128:191] (inputs) -> a[128:191]; accumulators, row sums, offsets -- while the pieces fly
     for r in range(64):
         P.append(I("acc_write_v", f"v_accvgpr_write_b32 a{A_Q + r}, v{128 + r}", dst=A_Q + r, src=128 + r))
     for a in range(128):
@@ -295,45 +387,37 @@ def program():
         P.append(I("v_movi", f"v_mov_b32 v{L[qb]}, 0", dst=L[qb], imm=0))
         P.append(I("v_movi", f"v_mov_b32 v{PEND[qb]}, 1.0", dst=PEND[qb], imm=0x3f800000))
         P.append(I("v_movi", f"v_mov_b32 v{PS[1][qb]}, 0", dst=PS[1][qb], imm=0))
-    # DMA: K(0) -> slot 0, V(0) -> slot 0, K(1) -> slot 1
-    pro = []
-    for u in dma_pieces("K", 0, "P0"):
-        pro.extend(u)
-    pro.append(I("s_add_s", "s_add_u32 s48, s48, s50", dst=48, a=48, b=50))
-    for u in dma_pieces("V", 0, ("T", 0)):
-        pro.extend(u)
-    pro.append(I("s_add_s", "s_add_u32 s49, s49, s50", dst=49, a=49, b=50))
-    for u in dma_pieces("K", 1, ("T", 0)):
-        pro.extend(u)
-    pro.append(I("s_add_s", "s_add_u32 s48, s48, s50", dst=48, a=48, b=50))
-    pro.append(need("P0"))
-    pro.append(BARRIER())
-    pro.extend(k_reads(0))  # K(0) -> AGPRs
-    pro.append(wait(lgkm=0))
-    P.extend(pro)
-    # iteration -1: scores of tile 0; behind its barrier: K(1) -> AGPRs, maxima + decision of tile 0, first exponentials, pieces of K(2) and V(1)
+    P.append(need("P0"))
+    P.append(BARRIER())
+    P.extend(k_reads(0))  # K(0) -> AGPRs
+    P.append(wait(lgkm=0))
+    # iteration -1: scores of tile 0; behind its barrier: K(1) -> AGPRs, maxima + decision of tile 0, first exponentials, pieces of K(4) and V(3)
     it, tl = iteration(-1, 100, pv=False)
     P.extend(it)
     tails.extend(tl)
     set_waits(P, resolve(P, []))
-    # the loop: two iterations (tile parities 0, 1); the same code serves its first pass (behind the prologue) and every later one
-    b0a, t0a = iteration(0, 200)
-    b1a, t1a = iteration(1, 300)
-    b0b, _ = iteration(2, 200)
-    b1b, _ = iteration(3, 300)
-    first, again = resolve(b0a + b1a, P), resolve(b0b + b1b, P + b0a + b1a)
-    set_waits(b0a + b1a, [min(x, y) for x, y in zip(first, again)])
-    loop = [I("label", "20:", name="LOOP")] + b0a + b1a + [I("s_sub", "s_sub_u32 s53, s53, 1", dst=53, a=53, imm=1), I("s_cmp_gt", "s_cmp_gt_u32 s53, 0", a=53, imm=0),
-                                                           I("cbranch_scc1", "s_cbranch_scc1 20b", target="LOOP")]
-    tails.extend(t0a + t1a)
-    # peeled: j = nt - 4 (full), nt - 3 (no K pieces), nt - 2 (no pieces, no K reads... K(nt) does not exist), nt - 1 (no scores)
+    # the loop: four iterations; the same code serves its first pass (behind the prologue) and every later one
+    def group(j0):
+        body, tl = [], []
+        for k in range(4):
+            it, t = iteration(j0 + k, 200 + 100 * k)
+            body.extend(it)
+            tl.extend(t)
+        return body, tl
+    ba, ta = group(0)
+    bb, _ = group(4)
+    first, again = resolve(ba, P), resolve(bb, P + ba)
+    set_waits(ba, [min(x, y) for x, y in zip(first, again)])
+    loop = [I("label", "20:", name="LOOP")] + ba + [I("s_sub", "s_sub_u32 s53, s53, 1", dst=53, a=53, imm=1), I("s_cmp_gt", "s_cmp_gt_u32 s53, 0", a=53, imm=0),
+                                                     I("cbranch_scc1", "s_cbranch_scc1 20b", target="LOOP")]
+    tails.extend(ta)
+    # peeled: j = nt - 8 + k.  K(j + 5) exists for k <= 2, V(j + 4) for k <= 3, K(j + 2) for k <= 5, tile j + 1 for k <= 6
     pe = []
-    for k, (flags, lab) in enumerate(((dict(), 400), (dict(dma_k=False), 500), (dict(dma_k=False, dma_v=False, kread=False), 600),
-                                       (dict(dma_k=False, dma_v=False, kread=False, qk=False, mx=False, exp_head=False, landed=False), 700))):
-        it, tl = iteration(4 + k, lab, **flags)  # (parities as j = nt - 4 + k with nt even)
+    for k in range(8):
+        it, tl = iteration(8 + k, 600 + 100 * k, dma_k=k <= 2, dma_v=k <= 3, kread=k <= 5, qk=k <= 6, mx=k <= 6, exp_head=k <= 6, landed=k <= 6)
         pe.extend(it)
         tails.extend(tl)
-    set_waits(pe, resolve(pe, P + b0a + b1a + b0b + b1b))
+    set_waits(pe, resolve(pe, P + ba + bb))
     end = []
     for qb in range(2):  # the last tile's row sums
         end.append(I("v_add", f"v_add_f32 v{L[qb]}, v{L[qb]}, v{PS[1][qb]}", dst=L[qb], a=L[qb], b=PS[1][qb]))
@@ -346,21 +430,27 @@ def program():
     return P + loop + pe + end + tails + [I("label", "99:", name="END")]
 
 
-CLOBBERS = [f"v{i}" for i in range(192, 226)] + [f"v{i}" for i in range(228, 238)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(48, 56)] + \
+CLOBBERS = [f"v{i}" for i in range(192, 226)] + [f"v{i}" for i in range(228, 238)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(48, 58)] + \
            ["m0", "vcc", "scc", "memory"]
 
 
 def emit(csrc):
     P = program()
     n_mfma = sum(1 for i in P if i.op == "mfma32")
+    k = [i for i, x in enumerate(P) if x.op == "split"][0]
+    with open(os.path.join(csrc, "attention5_dma.inc"), "w") as f:
+        f.write("// GENERATED by scripts/gen_attn5.py -- do not edit.  The DMA pieces of the first seven K / V tiles (an asm statement of its own, in front of the query loads).\n")
+        f.write("// same explicit registers as attention5_asm.inc\n")
+        f.write("\n".join('    "' + ins.text + '\\n"' for ins in P[:k]) + "\n")
+    P_all, P = P, P[k + 1:]
     with open(os.path.join(csrc, "attention5_asm.inc"), "w") as f:
         f.write("// GENERATED by scripts/gen_attn5.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
-        f.write(f"// {len(P)} instructions, {n_mfma} MFMAs (prologue, two-tile loop, four peeled tiles, out-of-line rescale blocks); registers: see the script's header.\n")
+        f.write(f"// {len(P)} instructions, {n_mfma} MFMAs (prologue, four-tile loop, eight peeled tiles, out-of-line rescale blocks); registers: see the script's header.\n")
         f.write("\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n")
     with open(os.path.join(csrc, "attention5_clobbers.inc"), "w") as f:
         f.write("// GENERATED by scripts/gen_attn5.py\n")
         f.write(", ".join('"' + c + '"' for c in CLOBBERS) + "\n")
-    return P
+    return P_all
 
 
 if __name__ == "__main__":
