@@ -186,6 +186,25 @@ def load() -> C.CDLL:
     return lib
 
 
+_attn_ws = {}
+
+
+def ensure_attention_workspace(device) -> None:
+    """Hand the library its attention workspace for the calling host thread (dk_attention_set_workspace: the partial results of the
+    key-split workgroups of csrc/attention5.hip), once per thread and device.  Optional for correctness: without it no launch is split."""
+    import threading
+
+    import torch
+    key = (threading.get_ident(), torch.device(device).index or 0)
+    if key in _attn_ws:
+        return
+    lib = load()
+    n = int(lib.dk_attention_workspace_bytes())
+    buf = torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+    check(lib.dk_attention_set_workspace(buf.data_ptr(), n), "dk_attention_set_workspace")
+    _attn_ws[key] = buf
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().dk_last_error().decode("utf-8", "replace")

@@ -19,10 +19,13 @@
 extern int g_dk_attn_mode;  // engine.hip; dk_tune_set("attn", v): -1 automatic; 4 = dk_attn2 (4 waves); 9 = dk_attn4 (8 waves, D = 128 only);
                             // 10 = dk_attn5 (one wave per SIMD, asm tile loop; D = 128, S % 256 == 0: other shapes fall back to 9)
 
-// lab only: trace buffer of attention4.hip's DK4_TRACE builds for the launches this host thread enqueues (scripts/attn_trace.py)
+// workspace of the launches this host thread enqueues (dk_attention_set_workspace): the partial results of attention5.hip's key-split
+// workgroups; lab: the trace buffer of attention4.hip's DK4_TRACE builds (scripts/attn_trace.py)
 static thread_local void* g_attn_ws = nullptr;
-void dk_set_attention_workspace(void* ws) { g_attn_ws = ws; }
+static thread_local size_t g_attn_ws_bytes = 0;
+void dk_set_attention_workspace(void* ws, size_t bytes) { g_attn_ws = ws, g_attn_ws_bytes = ws ? bytes : 0; }
 void* dk_get_attention_workspace() { return g_attn_ws; }
+size_t dk_get_attention_workspace_bytes() { return g_attn_ws_bytes; }
 
 int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   AttnParams p = p_in;

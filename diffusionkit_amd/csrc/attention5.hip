@@ -34,19 +34,31 @@ __global__ __launch_bounds__(256, 1) void dk_attn5_fwd_kernel(AttnParams p) {
   const int hi = lane >> 5, l31 = lane & 31;
   const int S = p.S;
   const int nq = (S + 255) / 256;
-  int t;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+  // Jobs: workgroups 0 .. a5_whole - 1 take whole query blocks; the others key range `part` of a5_split of one of the remaining blocks (the
+  // launch's last, partial round of the CUs -- dk_launch_attention5).  Inside each class the blocks follow each other on an XCD.
+  auto xcd_contiguous = [](int bid, int nwg) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  };
+  int t, part = 0, job = -1;
+  if ((int)blockIdx.x < p.a5_whole) {
+    t = xcd_contiguous(blockIdx.x, p.a5_whole);
+  } else {
+    job = xcd_contiguous(blockIdx.x - p.a5_whole, gridDim.x - p.a5_whole);
+    t = p.a5_whole + job / p.a5_split;
+    part = job % p.a5_split;
   }
   const unsigned row_bytes = (unsigned)p.ld * 2u;
   const int qblock = t % nq, head = (t / nq) % p.H, b = t / (nq * p.H);
   const int q0 = qblock * 256 + wave * 64;
+  // key tiles of this job: the S / 64 tiles in groups of four, dealt to the parts as evenly as possible
+  const int ng = S / 256, nparts = job < 0 ? 1 : p.a5_split;
+  const int g_lo = (part * ng) / nparts, g_hi = ((part + 1) * ng) / nparts;
+  const int tile0 = 4 * g_lo, nt = 4 * (g_hi - g_lo);
 
   const bf16_t* Qb = p.Q + (size_t)b * S * p.ld + head * D;
-  const char* Kb = (const char*)(p.K + (size_t)b * S * p.ld + head * D);
-  const char* Vb = (const char*)(p.V + (size_t)b * S * p.ld + head * D);
+  const char* Kb = (const char*)(p.K + ((size_t)b * S + (size_t)tile0 * 64) * p.ld + head * D);
+  const char* Vb = (const char*)(p.V + ((size_t)b * S + (size_t)tile0 * 64) * p.ld + head * D);
 
   // ---- LDS read addresses (attention4.hip) and the LDS-DMA source offsets of this wave's pieces ----
   u32x8 kaddr;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void dk_attn5_fwd_kernel(AttnParams p) {
   }
   const u32x4 rK = {(unsigned)(size_t)Kb, (unsigned)((size_t)Kb >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
   const u32x4 rV = {(unsigned)(size_t)Vb, (unsigned)((size_t)Vb >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
-  // the DMA pieces of the first seven K / V tiles leave BEFORE the query rows are fetched: one memory round trip for the whole prologue
+  // the DMA pieces of the first K tile leave BEFORE the query rows are fetched: one memory round trip for what the first scores need
   asm volatile(
 #include "attention5_dma.inc"
       :
@@ -143,23 +155,28 @@ __global__ __launch_bounds__(256, 1) void dk_attn5_fwd_kernel(AttnParams p) {
     }
   }
 
-  const int nt = S / 64;
   const int scale_bits = __float_as_int(p.scale);  // (the block forms c = scale * log2(e): p = 2^(s*c - m*c); rescale threshold 4 as in attention4.hip)
 
   f32x16 o[2][4];
-  u32x2 lsum;
+  u32x2 lsum, mcv;
   asm volatile(
 #include "attention5_asm.inc"
       : "={v[0:15]}"(o[0][0]), "={v[16:31]}"(o[0][1]), "={v[32:47]}"(o[0][2]), "={v[48:63]}"(o[0][3]), "={v[64:79]}"(o[1][0]), "={v[80:95]}"(o[1][1]),
-        "={v[96:111]}"(o[1][2]), "={v[112:127]}"(o[1][3]), "={v[226:227]}"(lsum), "+{v[128:143]}"(qv[0]), "+{v[144:159]}"(qv[1]), "+{v[160:175]}"(qv[2]),
+        "={v[96:111]}"(o[1][2]), "={v[112:127]}"(o[1][3]), "={v[226:227]}"(lsum), "={v[224:225]}"(mcv), "+{v[128:143]}"(qv[0]), "+{v[144:159]}"(qv[1]), "+{v[160:175]}"(qv[2]),
         "+{v[176:191]}"(qv[3])
-      : [koff] "s"(4 * 64 * (int)row_bytes), [voff] "s"(3 * 64 * (int)row_bytes), [tileb] "s"(64 * (int)row_bytes), [scale] "s"(scale_bits), [ntrip] "s"((nt - 8) / 4), [dbase] "s"(wave * 4096), "{v[238:245]}"(kaddr),
+      : [koff] "s"(64 * (int)row_bytes), [voff] "s"(0), [tileb] "s"(64 * (int)row_bytes), [scale] "s"(scale_bits), [ntrip] "s"((nt - 8) / 4), [dbase] "s"(wave * 4096), "{v[238:245]}"(kaddr),
         "{v[246:247]}"(vaddr), "{v[248:251]}"(dk), "{v[252:255]}"(dv), "{s[40:43]}"(rK), "{s[44:47]}"(rV)
       :
 #include "attention5_clobbers.inc"
   );
 
   // ---- normalise and store: lane owns query q0 + qb*32 + l31, d = dt*32 + 8g + 4hi + {0..3} (attention4.hip's tail, per query block) ----
+  // (the block above owns every VGPR: whatever lane-dependent value the tail needs is formed again from a FRESH lane id -- values carried
+  //  across the block would be spilled to scratch in front of it)
+  int lane_t;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+  {
+    const int lane = lane_t, hi = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l_run = __uint_as_float(lsum[qb]);
@@ -195,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void dk_attn5_fwd_kernel(AttnParams p) {
     }
   }
   if (p.O8 == nullptr) {
+    // (a key-range job leaves its 256 x 128 block of O / l in the workspace, rows of 256 B, and per row the exponent offset and l)
     // bf16 output: O^T accumulators -> wave-private LDS image (64 rows x 256 B, 16-byte chunk c of row r at position c ^ (r & 15)) -> whole
     // rows, 16 bytes per lane: a store instruction covers 4 complete rows (the per-lane 8-byte stores of attention4.hip's tail touch 32
     // rows per instruction).  Behind the tile loop's last barrier no wave reads the K / V rings any more.
@@ -216,36 +234,115 @@ __global__ __launch_bounds__(256, 1) void dk_attn5_fwd_kernel(AttnParams p) {
         }
     }
     // (a wave reads back its own image: program order + the compiler's lgkmcnt suffice)
-    bf16_t* const ob = p.O + ((size_t)b * S + q0) * p.ldo + head * D;
+    const int njobs = (int)gridDim.x - p.a5_whole;
+    bf16_t* const ob = job < 0 ? p.O + ((size_t)b * S + q0) * p.ldo + head * D : (bf16_t*)p.a5_ws + ((size_t)job * 256 + wave * 64) * D;
+    const size_t ldo = job < 0 ? (size_t)p.ldo : (size_t)D;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = 4 * i + (lane >> 4), pos = lane & 15;
       const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(lds + img + r * 256 + (pos << 4));
-      if (q0 + r < S) *(u32x4*)(ob + (size_t)r * p.ldo + ((pos ^ (r & 15)) << 3)) = v;
+      if (q0 + r < S) *(u32x4*)(ob + (size_t)r * ldo + ((pos ^ (r & 15)) << 3)) = v;
+    }
+    if (job >= 0) {
+      float* st = (float*)((char*)p.a5_ws + (size_t)njobs * 65536) + ((size_t)job * 256 + wave * 64) * 2;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float l_run = __uint_as_float(lsum[qb]);
+        const float l_row = l_run + __shfl_xor(l_run, 32, 64);  // (every lane takes part in the exchange)
+        if (hi == 0) *(f32x2*)(st + (qb * 32 + l31) * 2) = f32x2{__uint_as_float(mcv[qb]), l_row};
+      }
     }
   }
+  }
 }
+
+// the key ranges of one query block -> its rows of the output: O = sum_i w_i O_i / sum_i w_i with w_i = l_i 2^(mc_i - max mc); a thread owns
+// 8 columns of a row
+__global__ __launch_bounds__(256) void dk_attn5_merge_kernel(AttnParams p, int njobs) {
+  constexpr int D = 128;
+  const int blk = blockIdx.x >> 4, row = (blockIdx.x & 15) * 16 + (threadIdx.x >> 4), c8 = threadIdx.x & 15;
+  const int nq = (p.S + 255) / 256;
+  const int t = p.a5_whole + blk;
+  const int qblock = t % nq, head = (t / nq) % p.H, b = t / (nq * p.H);
+  const int q = qblock * 256 + row;
+  const float* st = (const float*)((const char*)p.a5_ws + (size_t)njobs * 65536);
+  float mc[4], l[4], mx = -3.0e38f;
+  for (int i = 0; i < p.a5_split; ++i) {
+    const f32x2 s2 = *(const f32x2*)(st + ((size_t)(blk * p.a5_split + i) * 256 + row) * 2);
+    mc[i] = s2[0], l[i] = s2[1];
+    mx = fmaxf(mx, mc[i]);
+  }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+  for (int i = 0; i < p.a5_split; ++i) {
+    const float w = l[i] * __builtin_amdgcn_exp2f(mc[i] - mx);
+    const u32x4 v = *(const u32x4*)((const bf16_t*)p.a5_ws + ((size_t)(blk * p.a5_split + i) * 256 + row) * D + c8 * 8);
+    wsum += w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo, hi2;
+      unpack2bf(v[e], lo, hi2);
+      acc[2 * e] += w * lo, acc[2 * e + 1] += w * hi2;
+    }
+  }
+  const float inv = 1.0f / wsum;
+  if (q < p.S) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+    *(u32x4*)(p.O + ((size_t)b * p.S + q) * p.ldo + head * D + c8 * 8) = o;
+  }
+}
+
+int g_dk_attn5_split = -1;  // dk_tune_set("attn_split", v): -1 automatic (needs the workspace), 0 never, 2 .. 4 that many key ranges for the last round's blocks
 
 bool dk_attention5_eligible(const AttnParams& p) {
   return p.D == 128 && p.bias == nullptr && p.S % 256 == 0 && p.S >= 12 * 64 && (size_t)p.S * p.ld * 2 < (1ull << 32);
 }
 
-template <bool QFUSE>
-static int launch_attn5(const AttnParams& p, hipStream_t stream) {
-  static DkDeviceOnce attr_once;
-  if (attr_once.first()) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn5_fwd_kernel<QFUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS_BYTES));
-    attr_once.mark();
-  }
-  const int nq = (p.S + 255) / 256;
-  const long tasks = (long)nq * p.H * p.B;
-  hipLaunchKernelGGL((dk_attn5_fwd_kernel<QFUSE>), dim3((unsigned)tasks), dim3(256), A5_LDS_BYTES, stream, p);
-  return 0;
-}
-
-int dk_launch_attention5(const AttnParams& p, hipStream_t stream) {
-  DK_REQUIRE(dk_attention5_eligible(p), "attention5: head_dim 128, no score bias, S a multiple of 256 and >= 768");
+int dk_launch_attention5(const AttnParams& p_in, hipStream_t stream) {
+  DK_REQUIRE(dk_attention5_eligible(p_in), "attention5: head_dim 128, no score bias, S a multiple of 256 and >= 768");
+  AttnParams p = p_in;
   const bool qfuse = p.qn_a != nullptr || p.q_rope != nullptr;
   if (qfuse) DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
-  return qfuse ? launch_attn5<true>(p, stream) : launch_attn5<false>(p, stream);
+  static DkDeviceOnce cu_once;
+  static int n_cu = 256;
+  if (cu_once.first()) {
+    int dev = 0;
+    DK_CHECK_HIP(hipGetDevice(&dev));
+    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    cu_once.mark();
+  }
+  // One workgroup per CU: a launch of nb blocks runs in ceil(nb / n_cu) rounds, the last one with nb % n_cu blocks.  Those blocks are split
+  // into s key ranges each (every range a multiple of four tiles, at least twelve) when that shortens the last round: it then takes
+  // ceil(tail * s / n_cu) / s of a block's time.  The partial results go through the workspace and dk_attn5_merge_kernel.
+  const int nb = ((p.S + 255) / 256) * p.H * p.B;
+  const int tail = nb % n_cu;
+  int split = 1;
+  if (tail > 0 && p.O8 == nullptr && g_dk_attn5_split != 0) {
+    // (measured, profiles/r05_attention5_lab.log: a workgroup costs ~14 us + 1.66 us per tile, and a last round on 152 of 256 CUs runs faster
+    //  than a full one -- FLUX, one image, gains nothing from three ranges in two sub-rounds; a tail that fits the CUs in ONE sub-round does:
+    //  batch 4: 96 blocks x 2)
+    for (int s = 2; s <= 4 && split == 1; ++s) {
+      if ((p.S / 256) / s < 3) break;  // >= 12 tiles per range
+      if (g_dk_attn5_split > 0 ? s == g_dk_attn5_split : (tail * s <= n_cu && tail * s * 10 >= n_cu * 6)) split = s;
+    }
+    void* ws = dk_get_attention_workspace();
+    if (split > 1 && (ws == nullptr || dk_get_attention_workspace_bytes() < (size_t)tail * split * (65536 + 2048))) split = 1;
+    p.a5_ws = ws;
+  }
+  p.a5_split = split;
+  p.a5_whole = split > 1 ? nb - tail : nb;
+  const int njobs = split > 1 ? tail * split : 0;
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn5_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_attn5_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS_BYTES));
+    attr_once.mark();
+  }
+  if (qfuse)
+    hipLaunchKernelGGL((dk_attn5_fwd_kernel<true>), dim3((unsigned)(p.a5_whole + njobs)), dim3(256), A5_LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((dk_attn5_fwd_kernel<false>), dim3((unsigned)(p.a5_whole + njobs)), dim3(256), A5_LDS_BYTES, stream, p);
+  if (njobs > 0) hipLaunchKernelGGL(dk_attn5_merge_kernel, dim3((unsigned)(tail * 16)), dim3(256), 0, stream, p, njobs);
+  return 0;
 }

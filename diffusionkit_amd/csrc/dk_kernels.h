@@ -165,15 +165,21 @@ struct AttnParams {
   unsigned char* O8 = nullptr;
   unsigned char* O8_scales = nullptr;
   int o8_ld = 0, o8_nblk = 0;
+  // attention5.hip, filled in by its launcher: workgroups 0 .. a5_whole - 1 take whole query blocks; the others one of a5_split key ranges of
+  // a block of the last, partial round of the CUs and leave (O / l in bf16, offset, l) in a5_ws for dk_attn5_merge_kernel
+  int a5_whole = 0, a5_split = 1;
+  void* a5_ws = nullptr;
 };
-void dk_set_attention_workspace(void* ws);  // attention.hip: thread-local lab trace buffer, picked up by dk_launch_attention
+void dk_set_attention_workspace(void* ws, size_t bytes = 0);  // attention.hip: thread-local workspace, picked up by dk_launch_attention
 void* dk_get_attention_workspace();
+size_t dk_get_attention_workspace_bytes();
 extern int g_dk_attn_mode;
 int dk_launch_attention(const AttnParams& p, hipStream_t stream);
 int dk_launch_attention2(const AttnParams& p, int waves, hipStream_t stream);  // attention2.hip (VALU-lean variant)
 int dk_launch_attention4(const AttnParams& p, hipStream_t stream);             // attention4.hip (the waves of a SIMD in opposite phases; D = 128, no score bias)
 bool dk_attention5_eligible(const AttnParams& p);                              // attention5.hip (one wave per SIMD, asm tile loop; D = 128, S % 256 == 0, no score bias)
 int dk_launch_attention5(const AttnParams& p, hipStream_t stream);
+extern int g_dk_attn5_split;
 
 // ---- single-head D = 512 attention of the VAE's mid block (attention512.hip) -------------------------------
 struct Attn512Params {

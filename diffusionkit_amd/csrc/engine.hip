@@ -41,6 +41,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm_skew") == 0) { g_dk_v4_skew = value; return 0; }
   if (strcmp(key, "attn") == 0) { g_dk_attn_mode = value; return 0; }
   if (strcmp(key, "attn_fuse_q") == 0) { g_dk_fuse_q = value; return 0; }
+  if (strcmp(key, "attn_split") == 0) { g_dk_attn5_split = value; return 0; }
   if (strcmp(key, "gemm_fuse_k") == 0) { g_dk_fuse_k = value; return 0; }
   if (strcmp(key, "gemm_fuse_q") == 0) { g_dk_fuse_qg = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
@@ -101,14 +102,14 @@ static int conv3x3_launch(const dk_conv_desc* d, void* workspace, hipStream_t st
 }
 extern "C" int dk_conv3x3_bf16(const dk_conv_desc* d, void* stream) { return conv3x3_launch(d, nullptr, S_(stream)); }
 
-// Round 5: the balanced launch these two served (pipelined D = 128 kernel, one workgroup per CU with a hand-off workspace) moved to
-// profiles/lab_kernels/attention3_pipelined.hip -- no default path took it (+6 % isolated, 0 inside the model).  The entry points stay for
-// ABI stability: no attention kernel of the library needs a workspace (0 bytes); a buffer handed in is only used by lab trace builds.
-extern "C" size_t dk_attention_workspace_bytes(void) { return 0; }
+// Workspace of the attention launches of this host thread.  attention5.hip splits the query blocks of a launch's last, partial round of the
+// CUs along the keys (FLUX, one image: 408 blocks on 256 CUs -- 152 blocks in three key ranges each fill the second round to two thirds
+// of a block's time); the partial results (bf16 O / l, offset, l per row) go through this buffer.  Without one (or with one too small for a
+// launch) the blocks are not split: same results up to the rounding of the partials, a longer last round.
+extern "C" size_t dk_attention_workspace_bytes(void) { return (size_t)1020 * (65536 + 2048); }  // <= 255 blocks x 4 key ranges
 extern "C" int dk_attention_set_workspace(void* workspace, size_t bytes) {
   DK_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 255) == 0, "attention workspace: 256-byte aligned (or NULL)");
-  (void)bytes;
-  dk_set_attention_workspace(workspace);
+  dk_set_attention_workspace(workspace, bytes);
   return 0;
 }
 

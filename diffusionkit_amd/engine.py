@@ -42,6 +42,9 @@ class MMDiTEngine:
     def __init__(self, config: MMDiTConfig, packed_weights: Dict[str, Tensor]):
         self.lib = _lib.load()
         self.config = config
+        dev0 = next(iter(packed_weights.values())).device
+        if dev0.type == "cuda":
+            _lib.ensure_attention_workspace(dev0)  # (the key-split workgroups of the D = 128 attention kernel)
         c = _lib.dk_mmdit_config()
         c.num_heads, c.depth_multimodal, c.depth_unified = config.num_heads, config.depth_multimodal, config.depth_unified
         c.hidden_size, c.mlp_ratio = config.hidden_size, config.mlp_ratio

@@ -188,6 +188,8 @@ def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None, worksp
     DK4_TRACE builds, dk_attention_set_workspace for the duration of the call)."""
     lib = _lib.load()
     _require_cuda(qkv, "qkv", BF)
+    if workspace is None:
+        _lib.ensure_attention_workspace(qkv.device)
     B, S, ld = qkv.shape
     h = H * D
     out = torch.empty(B, S, h, dtype=BF, device=qkv.device)
@@ -201,6 +203,7 @@ def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None, worksp
     finally:
         if workspace is not None:
             lib.dk_attention_set_workspace(None, 0)
+            _lib._attn_ws.clear()  # (the next call hands the library its regular workspace again)
     return out
 
 
@@ -220,6 +223,8 @@ def qk_norm_rope_(qkv: Tensor, H: int, D: int, qw: Optional[Tensor], kw: Optiona
     """In place on qkv [B, S, 3*H*D]; rope: f32 [S_pos, D/2, 2]."""
     lib = _lib.load()
     _require_cuda(qkv, "qkv", BF)
+    if workspace is None:
+        _lib.ensure_attention_workspace(qkv.device)
     B, S, ld = qkv.shape
     _lib.check(lib.dk_qk_norm_rope_bf16(qkv.data_ptr(), ld, 0, H * D, B * S, H, D, _ptr(qw), _ptr(kw), eps, _ptr(rope),
                                         S, S, pos_off, _stream()), "dk_qk_norm_rope_bf16")

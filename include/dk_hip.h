@@ -135,9 +135,10 @@ int dk_groupnorm_table_bf16(const void* x, int32_t B, int64_t HW, int32_t C, int
 int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
                       int32_t S, int32_t D, int32_t ld, int32_t ldo, float scale, void* stream);
 
-/* Kept for ABI stability (round 5): the balanced launch of the pipelined long-sequence kernel that used a hand-off workspace moved
- * to profiles/lab_kernels/ -- no default path took it.  dk_attention_workspace_bytes() is 0; dk_attention_set_workspace accepts a
- * 256-byte aligned buffer (or NULL) for THIS host thread and only lab trace builds of the attention kernel look at it. */
+/* Workspace of the attention launches THIS host thread enqueues (256-byte aligned, dk_attention_workspace_bytes() bytes; NULL: none).
+ * The one-wave-per-SIMD D = 128 kernel (attention5.hip) splits the query blocks of a launch's last, partial round of the CUs along the
+ * keys and merges the partial results through it.  Optional: without a workspace nothing is split (same results up to the bf16
+ * rounding of the partials; FLUX 1024^2, one image: ~10 % longer attention launches). */
 size_t dk_attention_workspace_bytes(void);
 int dk_attention_set_workspace(void* workspace, size_t bytes);
 

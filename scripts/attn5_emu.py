@@ -89,7 +89,7 @@ def run(P, nt, late, order, seed=0, spike=False, verbose=False, raw=False):
             rowpos = hf * 32 + (lane >> 1)
             kl = rowpos ^ (((dg & 1) << 2) | (dg & 3))
             V[G.DV + i] = kl * rb + (2 * dg + (lane & 1)) * 16
-        wv.S = {"%[koff]": 4 * 64 * rb, "%[voff]": 3 * 64 * rb, "%[tileb]": 64 * rb, "%[scale]": int(u32(np.float32(scale))), "%[ntrip]": (nt - 8) // 4, "%[dbase]": w * 4096}
+        wv.S = {"%[koff]": 64 * rb, "%[voff]": 0, "%[tileb]": 64 * rb, "%[scale]": int(u32(np.float32(scale))), "%[ntrip]": (nt - 8) // 4, "%[dbase]": w * 4096}
         waves.append(wv)
 
     def land_all(wv, keep):

@@ -21,8 +21,9 @@ for name, B, H, S in shapes:
     if os.environ.get("SPIKE"):
         qkv[:, S - 100, H * D:H * D + D] = qkv[:, 5, :D] * 3  # a key that lifts row 5's maximum late in the sequence
     outs, times = {}, {}
-    for mode in (9, 10):
-        ops.tune("attn", mode)
+    for mode in (9, 10, 11):  # 11: attention5 without the key split of the last round's blocks
+        ops.tune("attn", min(mode, 10))
+        ops.tune("attn_split", 0 if mode == 11 else -1)
         outs[mode] = ops.attention(qkv, H, D)
         torch.cuda.synchronize()
         best = 1e9
@@ -36,7 +37,8 @@ for name, B, H, S in shapes:
             best = min(best, e0.elapsed_time(e1) / 10)
         times[mode] = best
     ops.tune("attn", -1)
-    hs = min(H, 2)
+    ops.tune("attn_split", -1)
+    hs = H if S <= 2048 else min(H, 4)
     q, k, v = [qkv[:, :, i * H * D:i * H * D + hs * D].float().reshape(B, S, hs, D).permute(0, 2, 1, 3) for i in range(3)]
     ref = torch.softmax(q @ k.transpose(-1, -2) / D ** 0.5, -1) @ v
     ref = ref.permute(0, 2, 1, 3).reshape(B, S, hs * D)
@@ -46,6 +48,7 @@ for name, B, H, S in shapes:
     good = e10 < max(2.5 * e9, 2e-2) and bool(torch.isfinite(outs[10].float()).all())
     ok &= good
     fl = 4.0 * B * H * S * S * D
-    print(f"{name}: max err vs fp32 -- attn4 {e9:.2e}, attn5 {e10:.2e}; attn4 vs attn5 {d:.2e} {'ok' if good else 'WRONG'} | attn4 {times[9] * 1e3:7.1f} us {fl / times[9] / 1e9:6.0f} TF"
-          f" | attn5 {times[10] * 1e3:7.1f} us {fl / times[10] / 1e9:6.0f} TF", flush=True)
+    e11 = float((outs[11][:, :, :hs * D].float() - ref).abs().max())
+    print(f"{name}: max err vs fp32 -- attn4 {e9:.2e}, attn5 {e10:.2e} (unsplit {e11:.2e}); attn4 vs attn5 {d:.2e} {'ok' if good else 'WRONG'} | attn4 {times[9] * 1e3:7.1f} us {fl / times[9] / 1e9:6.0f} TF"
+          f" | attn5 {times[10] * 1e3:7.1f} us {fl / times[10] / 1e9:6.0f} TF | unsplit {times[11] * 1e3:7.1f} us {fl / times[11] / 1e9:6.0f} TF", flush=True)
 print("ALL OK" if ok else "MISMATCH", flush=True)

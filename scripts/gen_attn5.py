@@ -352,8 +352,8 @@ def program():
     """nt = S / 64 tiles, a multiple of 4, >= 12.  Prologue (K(0..3), V(0..2); iteration -1: the scores of tile 0), a four-tile loop over
     j = 0 .. nt - 9, eight peeled iterations."""
     P, tails = [], []
-    # ---- block 1 (its own asm statement, in front of the query loads): the first seven tiles' DMA pieces: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2)
-    # (the order the waits retire them in); the loads of the query rows behind them share their round trip
+    # ---- block 1 (its own asm statement, in front of the query loads): the DMA pieces of K(0); the loads of the query rows behind them share
+    # their round trip.  (All seven prologue tiles in front of the query loads made every workgroup wait for 176 KB: the counter retires in order.)
     for d, s in ((48, "0"), (49, "0"), (50, "%[tileb]"), (55, "%[dbase]")):
         P.append(I("s_mov", f"s_mov_b32 s{d}, {s}", dst=d, src=s))
     pro = []
@@ -364,14 +364,16 @@ def program():
         r = 48 if opnd == "K" else 49
         pro.append(I("s_add_s", f"s_add_u32 s{r}, s{r}, s50", dst=r, a=r, b=50))
     issue("K", 0, "P0")
-    for t in range(3):
-        issue("K", t + 1, ("T", t - 4))
-        issue("V", t, ("T", t - 4))
     P.extend(pro)
     P.append(I("split", None))
     # ---- block 2
     for d, s in ((48, "%[koff]"), (49, "%[voff]"), (50, "%[tileb]"), (52, "0x40b8aa3b"), (53, "%[ntrip]"), (55, "%[dbase]"), (56, "0"), (57, "0")):  # s52 = 4 * log2(e)
         P.append(I("s_mov", f"s_mov_b32 s{d}, {s}", dst=d, src=s))
+    pro = []
+    for t in range(3):  # K(1) V(0) | K(2) V(1) | K(3) V(2): the order the waits retire them in
+        issue("K", t + 1, ("T", t - 4))
+        issue("V", t, ("T", t - 4))
+    P.extend(pro)
     # c = scale * log2(e) into s51 (a float product has no scalar instruction: through a VGPR)
     P.append(I("v_mov_s", f"v_mov_b32 v{TMP[0]}, %[scale]", dst=TMP[0], src="%[scale]"))
     P.append(I("v_mul_lit", f"v_mul_f32 v{TMP[0]}, 0x3fb8aa3b, v{TMP[0]}", dst=TMP[0], src=TMP[0], lit=0x3fb8aa3b))
@@ -430,7 +432,7 @@ def program():
     return P + loop + pe + end + tails + [I("label", "99:", name="END")]
 
 
-CLOBBERS = [f"v{i}" for i in range(192, 226)] + [f"v{i}" for i in range(228, 238)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(48, 58)] + \
+CLOBBERS = [f"v{i}" for i in range(192, 224)] + [f"v{i}" for i in range(228, 238)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(48, 58)] + \
            ["m0", "vcc", "scc", "memory"]
 
 
@@ -439,7 +441,7 @@ def emit(csrc):
     n_mfma = sum(1 for i in P if i.op == "mfma32")
     k = [i for i, x in enumerate(P) if x.op == "split"][0]
     with open(os.path.join(csrc, "attention5_dma.inc"), "w") as f:
-        f.write("// GENERATED by scripts/gen_attn5.py -- do not edit.  The DMA pieces of the first seven K / V tiles (an asm statement of its own, in front of the query loads).\n")
+        f.write("// GENERATED by scripts/gen_attn5.py -- do not edit.  The DMA pieces of the first K tile (an asm statement of its own, in front of the query loads).\n")
         f.write("// same explicit registers as attention5_asm.inc\n")
         f.write("\n".join('    "' + ins.text + '\\n"' for ins in P[:k]) + "\n")
     P_all, P = P, P[k + 1:]

@@ -386,7 +386,7 @@ def test_attention_kernels_agree_inside_the_model(dev, B, side):
     try:
         for fq in (1, 0):
             ops.tune("attn_fuse_q", fq)
-            for mode in (9, 4):
+            for mode in (9, 4, 10):  # (10: the one-wave-per-SIMD kernel; side 104's S = 2960 is not a multiple of 256: it falls back to 9)
                 ops.tune("attn", mode)
                 outs[(mode, fq)] = eng.forward_tokens(tok, text.to(dev, BF), 1).float().cpu()
     finally:

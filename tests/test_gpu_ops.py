@@ -447,6 +447,75 @@ def test_attention_kernel_variants(dev, mode, B, H, S, D):
     assert max_abs(ref, y.float()) < 0.03
 
 
+@pytest.mark.parametrize("B,H,S", [(1, 2, 768), (2, 3, 1024), (1, 2, 2304), (1, 24, 4352)])
+def test_attention5_one_wave_per_simd(dev, B, H, S):
+    """attention5.hip (dk_tune_set("attn", 10): one wave per SIMD, 4 waves x 64 queries, K / V by LDS-DMA, generated asm tile loop; the
+    automatic choice at D = 128, S >= 2048, S % 256 == 0) against the oracle and against the phase-alternating kernel: 12 key tiles (one
+    pass of the four-tile loop), 16, 36, and FLUX.1-schnell's 4352 tokens x 24 heads (408 query blocks: two rounds of the CUs)."""
+    from diffusionkit_amd import ops
+    D, h = 128, H * 128
+    qkv = randn(B, S, 3 * h, seed=33)
+    outs = {}
+    for mode in (9, 10):
+        try:
+            ops.tune("attn", mode)
+            outs[mode] = ops.attention(g(qkv, dev), H, D)
+        finally:
+            ops.tune("attn", -1)
+    hs = min(H, 3)  # (the oracle over the first heads; every head against the other kernel)
+    q, k, v = (qkv[..., i * h:i * h + hs * D].reshape(B, S, hs, D).transpose(1, 2) for i in range(3))
+    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(B, S, hs * D)
+    assert rel_l2(ref, outs[10][..., :hs * D].float()) < 6e-3
+    assert max_abs(ref, outs[10][..., :hs * D].float()) < 0.03
+    assert max_abs(outs[9].float(), outs[10].float()) < 4e-3  # (same algorithm; the row sums are added in another order)
+
+
+@pytest.mark.parametrize("split", [2, 3, 4])
+def test_attention5_key_split_of_the_last_round(dev, split):
+    """attention5.hip's key-split jobs (dk_tune_set("attn_split", n): the query blocks of a launch's last, partial round of the CUs in n key
+    ranges each, partial results through the workspace, dk_attn5_merge_kernel) against the unsplit launch and the oracle; a spiked key in the
+    last range (the ranges end at different exponent offsets: the merge weights l_i 2^(mc_i - max mc))."""
+    from diffusionkit_amd import ops
+    B, H, S, D = 1, 2, 3072, 128
+    h = H * D
+    qkv = randn(B, S, 3 * h, seed=34, scale=0.7)
+    qkv[0, 3000, h:h + D] = bf16r(qkv[0, 77, :D] * 5.0)  # key 3000 aligned with query 77 of head 0
+    outs = {}
+    try:
+        ops.tune("attn", 10)
+        for s_ in (0, split):
+            ops.tune("attn_split", s_)
+            outs[s_] = ops.attention(g(qkv, dev), H, D)
+    finally:
+        ops.tune("attn", -1)
+        ops.tune("attn_split", -1)
+    q, k, v = (qkv[..., i * h:(i + 1) * h].reshape(B, S, H, D).transpose(1, 2) for i in range(3))
+    ref = om.sdpa(q, k, v, 1.0 / math.sqrt(D), Prec()).transpose(1, 2).reshape(B, S, h)
+    assert rel_l2(ref, outs[split].float()) < 6e-3
+    assert not torch.equal(outs[0], outs[split])  # (the switch does select the split launch: the partials are rounded to bf16)
+    assert max_abs(outs[0].float(), outs[split].float()) < 0.02 * float(ref.abs().max()) + 4e-3
+
+
+def test_attention5_spiked_key_forces_rescale(dev):
+    """a key that dominates late in the sequence: attention5.hip records the rescale factor at the decision and applies it once the previous
+    tile's P.V is complete (guide rule 26); fp64 reference; a second spike in the very last tile"""
+    from diffusionkit_amd import ops
+    B, H, S, D = 1, 1, 1024, 128
+    qkv = randn(B, S, 3 * D, seed=31, scale=0.5)
+    qkv[0, 700, D:2 * D] = bf16r(qkv[0, 7, :D] * 6.0)
+    qkv[0, 1023, D:2 * D] = bf16r(qkv[0, 300, :D] * 6.0)
+    q, k, v = (qkv[..., i * D:(i + 1) * D].double() for i in range(3))
+    p = torch.softmax(q[0] @ k[0].t() / math.sqrt(D), dim=-1)
+    ref = (p @ v[0])[None]
+    assert float(p[7, 700]) > 0.9 and float(p[300, 1023]) > 0.9
+    try:
+        ops.tune("attn", 10)
+        y = ops.attention(g(qkv, dev), H, D)
+    finally:
+        ops.tune("attn", -1)
+    assert rel_l2(ref, y.float()) < 6e-3
+
+
 @pytest.mark.parametrize("B,T", [(1, 64), (2, 96), (1, 100), (1, 1000), (2, 4096)])
 def test_attention_d512_flash(dev, B, T):
     """the VAE mid block's single-head D = 512 attention (vae.py:28-57) on the role-split flash kernel (attention512.hip): ragged
