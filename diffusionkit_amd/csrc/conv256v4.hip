@@ -233,8 +233,10 @@ bool dk_conv256v4_eligible(const ConvHaloParams& p) {
 
 bool dk_conv256v4_wanted(const ConvHaloParams& p) {
   if (g_dk_conv_v4 == 0 || !dk_conv256v4_eligible(p)) return false;
-  const long tiles = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.O >> 8);
-  return g_dk_conv_v4 == 2 || tiles >= 256;  // (one workgroup per CU: a launch of 128 tiles leaves half the chip idle -- conv_halo.hip's 128-column tiles fill it)
+  // one workgroup per CU: a launch of 128 tiles leaves half the chip idle -- conv_halo.hip's 128-column tiles fill it.  The rule looks at ONE
+  // image: the two kernels sum their GroupNorm partials in different orders, and a batch must decode to what its images decode to alone
+  const long tiles = (long)(p.H >> 4) * (p.W >> 4) * (p.O >> 8);
+  return g_dk_conv_v4 == 2 || tiles >= 256;
 }
 
 int dk_launch_conv256v4(const ConvHaloParams& p, hipStream_t stream) {

@@ -223,8 +223,6 @@ def qk_norm_rope_(qkv: Tensor, H: int, D: int, qw: Optional[Tensor], kw: Optiona
     """In place on qkv [B, S, 3*H*D]; rope: f32 [S_pos, D/2, 2]."""
     lib = _lib.load()
     _require_cuda(qkv, "qkv", BF)
-    if workspace is None:
-        _lib.ensure_attention_workspace(qkv.device)
     B, S, ld = qkv.shape
     _lib.check(lib.dk_qk_norm_rope_bf16(qkv.data_ptr(), ld, 0, H * D, B * S, H, D, _ptr(qw), _ptr(kw), eps, _ptr(rope),
                                         S, S, pos_off, _stream()), "dk_qk_norm_rope_bf16")

@@ -392,8 +392,12 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
  * multi-round launches in 0.25 us steps (-1: none); "gemm_mf": 8 / 7 = 256- / 224-row
  * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
- * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise); "attn_fuse_q": 0 = stand-alone query
- * QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form;
+ * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise; 10 one-wave-per-SIMD kernel with the generated asm
+ * tile loop: head_dim 128, S a multiple of 256 and >= 768, falls back to 9 otherwise -- the automatic choice from S = 2048 on);
+ * "attn_split": key ranges of the one-wave-per-SIMD kernel's last-round query blocks (-1 automatic, 0 never, 2..4);
+ * "attn_fuse_q": 0 = stand-alone query QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form;
+ * "conv_v4": the fused VAE convolutions with >= 256 output channels on the one-wave-per-SIMD kernel (1 where one image fills the
+ * CUs, 0 never, 2 wherever eligible);
  * "pitch_min_k": rows of at least this many elements are stored padded (dk_weight_pitch).
  * Returns 0, or -1 for an unknown key. */
 int dk_tune_set(const char* key, int32_t value);

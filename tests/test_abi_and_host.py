@@ -159,13 +159,15 @@ def test_tune_keys_and_workspace_sizes():
     workspace-size queries answer without a GPU."""
     from diffusionkit_amd import _lib
     lib = _lib.load()
-    for key in (b"gemm", b"gemm_v4", b"gemm_skew", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_fuse_q", b"conv_halo"):
-        assert lib.dk_tune_set(key, -1 if key not in (b"gemm_fuse_k", b"attn_fuse_q") else 1) == 0, key
+    for key in (b"gemm", b"gemm_v4", b"gemm_skew", b"gemm_mf", b"gemm_split", b"gemm_fuse_k", b"gemm_fuse_q", b"attn", b"attn_fuse_q", b"attn_split", b"conv_halo",
+                b"conv_v4"):
+        assert lib.dk_tune_set(key, -1 if key not in (b"gemm_fuse_k", b"attn_fuse_q", b"conv_v4") else 1) == 0, key
     assert lib.dk_tune_set(b"gemm_sched", 0) == -1  # a knob of the removed kernel generations
     assert b"unknown tuning key" in lib.dk_last_error()
     assert lib.dk_gemm_workspace_bytes() == 256 * 256 * 256 * 4 + 4096
     assert lib.dk_tune_set(b"attn_balance", 1) == -1 and lib.dk_tune_set(b"vae_attn", 0) == -1  # round 5: moved to profiles/lab_kernels
-    assert lib.dk_attention_workspace_bytes() == 0  # (kept for ABI stability: no attention kernel of the library needs a workspace)
+    # the partial results of attention5.hip's key-split workgroups: <= 255 blocks x 4 key ranges x (256 rows x 256 B + 256 x (offset, l))
+    assert lib.dk_attention_workspace_bytes() == 1020 * (65536 + 2048)
     assert lib.dk_attention_set_workspace(None, 0) == 0
 
 
