@@ -6,7 +6,8 @@
 The decoder's launch order is fixed (vae.py:336-401; diffusionkit_amd/csrc/engine.hip: dk_vae_decode): conv_in, mid resnet, mid attention,
 mid resnet, then the up blocks from the deepest (3 resnets = 6 convs each; an upsampling conv behind all but the last), conv_out.  The
 fused stages run dk_conv_halo_kernel<128> (GroupNorm-apply + SiLU on the way into the LDS halo tile; the 1x1 shortcut of a
-channel-changing resnet rides in its conv2 as extra K-tiles), conv_out dk_conv_halo_kernel<16, true> (+ clip + uint8).
+channel-changing resnet rides in its conv2 as extra K-tiles) or, with >= 256 output channels where one image fills the CUs,
+dk_conv256v4_kernel (one wave per SIMD, asm body); conv_out dk_conv_halo_kernel<16, true> (+ clip + uint8).
 """
 import csv
 import glob
@@ -44,7 +45,7 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    conv = [(s, e) for s, e, k in rows if "dk_conv_halo_kernel<128" in k]
+    conv = [(s, e, k) for s, e, k in rows if "dk_conv_halo_kernel<128" in k or "dk_conv256v4_kernel" in k]
     st = stages()
     n = len(st)
     assert len(conv) % n == 0 and conv, f"{len(conv)} conv_halo<128> launches, expected a multiple of {n}"
@@ -58,10 +59,10 @@ def main():
     busy = sum(e - s for s, e, k in inside) / 1e3
     print(f"# VAE decode 128 x 128 latent -> 1024 x 1024, per launch (last of {decodes} decodes in the trace)\n")
     print(f"whole decode: {(t_end - inside[0][0]) / 1e3:.0f} us wall, kernels {busy:.0f} us ({len(inside)} launches)\n")
-    print("| # | stage | pixels | C_in -> C_out | GFLOP | us | TFLOP/s | of 2500 |\n|---|---|---|---|---|---|---|---|")
+    print("| # | stage | pixels | C_in -> C_out | GFLOP | us | TFLOP/s | of 2500 | kernel |\n|---|---|---|---|---|---|---|---|---|")
     tot_f = tot_t = 0.0
     by_res = {}
-    for i, ((name, H, cin, cout, xk), (s, e)) in enumerate(zip(st, last)):
+    for i, ((name, H, cin, cout, xk), (s, e, kn)) in enumerate(zip(st, last)):
         fl = 2.0 * H * H * (9 * cin + xk) * cout
         us = (e - s) / 1e3
         tot_f += fl
@@ -71,14 +72,14 @@ def main():
         by_res[key][0] += fl
         by_res[key][1] += us
         by_res[key][2] += 1
-        print(f"| {i + 1} | `{name}` | {H}² | {cin}{' (+' + str(xk) + ' shortcut)' if xk else ''} -> {cout} | {fl / 1e9:.0f} | {us:.1f} | {fl / us / 1e6:.0f} | {fl / us / 1e6 / 2500:.3f} |")
+        print(f"| {i + 1} | `{name}` | {H}² | {cin}{' (+' + str(xk) + ' shortcut)' if xk else ''} -> {cout} | {fl / 1e9:.0f} | {us:.1f} | {fl / us / 1e6:.0f} | {fl / us / 1e6 / 2500:.3f} | {'conv256v4' if 'conv256v4' in kn else 'conv_halo'} |")
     print(f"| | **all 31** | | | {tot_f / 1e9:.0f} | {tot_t:.0f} | {tot_f / tot_t / 1e6:.0f} | {tot_f / tot_t / 1e6 / 2500:.3f} |")
     print("\n| shape class | launches | GFLOP | us | TFLOP/s |\n|---|---|---|---|---|")
     for (H, cin, cout), (fl, us, cnt) in sorted(by_res.items()):
         print(f"| {H}² {cin} -> {cout} | {cnt} | {fl / 1e9:.0f} | {us:.0f} | {fl / us / 1e6:.0f} |")
     other = {}
     for s, e, k in inside:
-        if "dk_conv_halo_kernel<128" in k:
+        if "dk_conv_halo_kernel<128" in k or "dk_conv256v4_kernel" in k:
             continue
         kk = k.split("(")[0].replace("void ", "")
         other.setdefault(kk, [0.0, 0])
