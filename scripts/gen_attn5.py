@@ -7,19 +7,22 @@ a workgroup = 4 waves = 256 query rows, a wave owns 64 of them (two 32-row block
   a[192:255]  K fragments of the tile whose scores come next, (half, kk) at 192 + (half*8 + kk)*4
   v[0:63] / v[64:127]  two score sets (tile parity), block (qb, half) at base + (qb*2 + half)*16     v[128:159] P fragments (qb, n)
   v[160:223]  V^T fragments (dt, n) of the tile being multiplied        v[224:255] softmax state + addresses (see below)
-K / V tiles (64 keys) arrive by LDS-DMA into two-slot rings (K one and a half tiles ahead of its reads, V one): a wave issues 4 + 4 pieces per tile.
+K / V tiles (64 keys) arrive by LDS-DMA into four-slot rings (K at 0, V at 65536; a piece has 2.5 - 3 tiles to land): a wave issues 4 + 4 pieces
+per tile.  Temporaries of the row maxima live in the OTHER score set (dead between the packs of a tile and the scores of the tile after next).
 
 Iteration j (one barrier, in the middle):
   phase 1, 32 MFMAs: S(j+1)^T = K(j+1) Q^T      beside: V(j) tr-reads, the second half of the exponentials of tile j, P(j) -> bf16
-  -- vmcnt(0): K(j+2), V(j+1) landed -- barrier: every wave has read V(j) and (a phase ago) K(j+1)'s successor slot is free --
+  -- vmcnt: K(j+2), V(j+1) landed (the pieces of the last two iterations may fly) -- barrier: every wave has read V(j); K(j+1)'s slot is free --
   phase 2, 32 MFMAs: O^T += V(j)^T P(j)^T        beside: K(j+2) -> AGPRs, row maxima of S(j+1) + the rescale decision, the first half of the
-                                                  exponentials of tile j+1, the DMA pieces of K(j+3) and V(j+2)
-The running maximum moves only when a score exceeds it by the threshold (attention4.hip's deferred rescale).  The decision for tile t is taken
-while P(t-1) V(t-1) is still in flight, so it only RECORDS the factor (pend) and switches the exponent offset; the accumulators and the row
-sums -- everything still at the old scale, P(t-1)'s products and sums included -- are multiplied once, at the head of the next phase 1, when
-that P.V is complete (a rare, out-of-line block).
+                                                  exponentials of tile j+1, the DMA pieces of K(j+5) and V(j+4)
+The exponent offset of a row moves only when a score exceeds it by the threshold (attention4.hip's deferred rescale), per row and without a
+branch (v_cmp / v_cndmask; the factor is exactly 1 otherwise).  The decision for tile t is taken while P(t-1) V(t-1) is still in flight, so it
+only RECORDS the factor (pend) and switches the offset; the accumulators and the row sums -- everything still at the old scale, P(t-1)'s
+products and sums included -- are multiplied once, at the head of the next phase 1, when that P.V is complete (a rare, out-of-line block
+behind a scalar test of s[56:57]).  Program: a first asm statement with K(0)'s pieces (in front of the query loads), then prologue (K(1..3),
+V(0..2), tile -1 = the scores of tile 0), a four-tile loop (ring slot x score-set parity), eight peeled tiles.
 
-  python scripts/gen_attn5.py            write diffusionkit_amd/csrc/attention5_asm.inc, attention5_clobbers.inc
+  python scripts/gen_attn5.py            write diffusionkit_amd/csrc/attention5_dma.inc, attention5_asm.inc, attention5_clobbers.inc
   python scripts/gen_attn5.py --check    also run the instruction-level emulator (4 waves x 64 lanes) against an fp64 softmax(Q K^T) V
 
 v[224:225] mc = running max * c   v[226:227] l   v[228:231] psum[parity][qb]   v[232:233] pend   v[234:237] temporaries
