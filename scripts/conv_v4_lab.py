@@ -17,6 +17,10 @@ BF = torch.bfloat16
 shapes = [("small gn+res 128->256 @32x48 B2", 2, 32, 48, 128, 256, True, True, False),
           ("small plain ups 128->256 @32x48 B2", 2, 32, 48, 128, 256, False, False, True),
           ("small gn 256->512 @48x48", 1, 48, 48, 256, 512, True, False, False),
+          ("small gn+res 128->128 @32x48 B2", 2, 32, 48, 128, 128, True, True, False),
+          ("small plain ups 256->128 @32x32", 1, 32, 32, 256, 128, False, False, True),
+          ("128->128 @1024^2 gn+res", 1, 1024, 1024, 128, 128, True, True, False),
+          ("256->128 @1024^2 gn", 1, 1024, 1024, 256, 128, True, False, False),
           ("512->512 @128^2 gn+res", 1, 128, 128, 512, 512, True, True, False),
           ("512->512 @256^2 gn+res", 1, 256, 256, 512, 512, True, True, False),
           ("512->512 @256^2 ups", 1, 256, 256, 512, 512, False, False, True),

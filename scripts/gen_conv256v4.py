@@ -55,6 +55,12 @@ WF = [96, 128]
 R0, SC, SH, TA = 160, 204, 212, 220
 NITEM = 11
 VM_OPS = ("dma", "vload")
+# Two tile forms.  CFG 0: 16 x 16 pixels x 256 channels, waves 2 x 2 of 128 x 128 (8 pixel-row fragments), weight K-tiles of 256 rows in a two-slot
+# ring (xor toggle).  CFG 1 (128-channel stages): 16 x 16 pixels x 128 channels, waves 4 x 1 of 64 pixels x 128 channels (4 pixel-row fragments,
+# 64 MFMAs per K-tile), weight K-tiles of 128 rows in a THREE-slot ring: nine taps per chunk = slot tap % 3 as an immediate, no toggles, and the
+# pieces of K-tile t + 3 leave right behind the barrier that releases K-tile t's slot (two K-tiles to land: a K-tile is half as long here).
+CFG = 0
+MFX = 8
 
 
 def xoff(tap, k, kk):
@@ -62,9 +68,12 @@ def xoff(tap, k, kk):
     return ((k + dy) * 18 + dx) * H_ROWB + kk * 64
 
 
-def wdma(g, tag):
-    hh, j, u = g & 1, (g >> 1) & 1, g >> 2
-    const = hh * 16384 + (u * 16 + j * 8) * 128
+def wdma(g, tag, slot=0):
+    if CFG == 1:  # piece g (0..3) of a wave: 8 rows of the 128-row K-tile, ring slot `slot`
+        const = slot * 16384 + g * 1024
+    else:
+        hh, j, u = g & 1, (g >> 1) & 1, g >> 2
+        const = hh * 16384 + (u * 16 + j * 8) * 128
     return [I("s_add", f"s_add_u32 m0, s71, {const}", dst="m0", a=71, imm=const),
             I("dma", f"buffer_load_dwordx4 v{WP + g}, s[64:67], s68 offen lds", opnd="W", vo=WP + g, tag=tag)]
 
@@ -149,13 +158,69 @@ def halo_stream(xform):
 
 def w_advance(tap_issued):
     """behind the pieces of the weight K-tile of tap `tap_issued`: the K offset moves on to the next tap (or to tap 0 of the next chunk), the ring flips"""
-    return [I("s_add_s", f"s_add_u32 s68, s68, s{76 if tap_issued == 8 else 75}", dst=68, a=68, b=76 if tap_issued == 8 else 75),
-            I("s_xor", f"s_xor_b32 s71, s71, {W_TOG:#x}", dst=71, imm=W_TOG)]
+    adv = [I("s_add_s", f"s_add_u32 s68, s68, s{76 if tap_issued == 8 else 75}", dst=68, a=68, b=76 if tap_issued == 8 else 75)]
+    if CFG == 0:
+        adv.append(I("s_xor", f"s_xor_b32 s71, s71, {W_TOG:#x}", dst=71, imm=W_TOG))
+    return adv
+
+
+def ktile1(tap, wtile, dma_on, next_on, extra=None, drain=False):
+    """CFG 1: 64 MFMAs (8 weight fragments x 4 pixel-row fragments x 2 slices); weight ring slot = tap % 3; the pieces of K-tile wtile + 3 go
+    into the slot this K-tile releases"""
+    S, T = 32, 64
+    mf = [mfma(j, k, 0) for j in range(8) for k in range(4)] + [mfma(j, k, 1) for j in range(8) for k in range(4)]
+    slots = [[] for _ in range(T + 1)]
+
+    def put(m, ins):
+        slots[m].extend(ins if isinstance(ins, list) else [ins])
+
+    ws = (tap % 3) * 16384
+    for k in range(4):
+        put(1 + k, ds_read(XF[1] + 4 * k, RXB, xoff(tap, k, 1)))
+    for j in range(8):
+        put(5 + j, ds_read(WF[1] + 4 * j, RW[1], ws + j * 2048))
+    if drain:
+        for n in range(8):
+            put(13 + n, ds_read(R0 + 4 * n, BA, n * 64))
+    put(21, wait(lgkm=0))
+    put(22, BARRIER())  # every wave has read both slices of W(wtile): its slot is free (tap 8: and every wave's halo stores of the next chunk are done)
+    if dma_on:
+        for g in range(4):
+            a, b = wdma(g, ("W", wtile + 3), tap % 3)
+            slots[24 + 4 * g - 1].append(a)
+            slots[24 + 4 * g].append(b)
+    for m, ins in sorted((extra or {}).items()):
+        put(m, ins)
+    if next_on:
+        ntap = (tap + 1) % 9
+        nws = (ntap % 3) * 16384
+        for k in range(4):
+            put(32 + 2 * k, ds_read(XF[0] + 4 * k, RXA, xoff(ntap, k, 0)))
+        put(42, need(("W", wtile + 1)))
+        put(43, BARRIER())  # W(wtile + 1) has landed for every wave
+        for j in range(8):
+            put(44 + j, ds_read(WF[0] + 4 * j, RW[0], nws + j * 2048))
+    if dma_on:
+        slots[T].extend(w_advance((tap + 3) % 9))
+    if drain:
+        for j in range(7):
+            for g in range(4):
+                slots[S + 4 * (j + 1) + g].extend(drain_tile(j, g, g))
+    out = []
+    for m in range(T):
+        out.extend(slots[m])
+        out.append(mf[m])
+    out.extend(slots[T])
+    if next_on:
+        out.append(wait(lgkm=0))
+    return out
 
 
 def ktile(tap, wtile, dma_on, next_on, extra=None, drain=False):
     """K-tile `wtile` = tap `tap` of the current chunk; issues the pieces of K-tile wtile + 2, pre-reads the first slice of wtile + 1.
     extra: {slot: [instructions]} of the chunk-level work (halo loads, transform stream, slot toggles)"""
+    if CFG == 1:
+        return ktile1(tap, wtile, dma_on, next_on, extra, drain)
     S, T = 64, 128
     mf = [mfma(j, k, 0) for j in range(8) for k in range(8)] + [mfma(j, k, 1) for j in range(8) for k in range(8)]
     slots = [[] for _ in range(T + 1)]
@@ -210,10 +275,15 @@ def chunk_body(n, xform, last):
     out = []
     stream = [] if last else halo_stream(xform)
     # positions of the stream: (tap 1, slot 47) .. (tap 8, slot 30), one unit per MFMA gap, evenly spread
-    pos = [(1, m) for m in range(47, 128)] + [(t, m) for t in range(2, 8) for m in range(128)] + [(8, m) for m in range(31)]
-    if not xform:
-        pos = [(1, m) for m in range(47, 128, 4)][:len(stream)]
-    assert len(stream) <= len(pos)
+    if CFG == 1:  # (two units per MFMA gap on average: 576 gaps per chunk for the same halo)
+        pos = [(1, m) for m in range(24, 64)] + [(t, m) for t in range(2, 8) for m in range(64)] + [(8, m) for m in range(15)]
+        if not xform:
+            pos = [(1, m) for m in range(24, 64, 3)][:len(stream)]
+    else:
+        pos = [(1, m) for m in range(47, 128)] + [(t, m) for t in range(2, 8) for m in range(128)] + [(8, m) for m in range(31)]
+        if not xform:
+            pos = [(1, m) for m in range(47, 128, 4)][:len(stream)]
+        assert len(stream) <= len(pos)
     where = {}
     for s, u in enumerate(stream):
         t, m = pos[(s * len(pos)) // len(stream)]
@@ -223,18 +293,22 @@ def chunk_body(n, xform, last):
         if not last:
             if tap == 0:
                 loads = halo_loads(xform, ("H", n + 1))
-                at = ([2, 4, 6, 8] if xform else []) + [10 + 3 * i for i in range(NITEM)]  # scale / shift first, then the items: 10, 13, ..., 40
+                if CFG == 1:
+                    at = ([24, 26, 28, 30] if xform else []) + [32 + 2 * i for i in range(NITEM)]  # behind the weight pieces of this K-tile
+                else:
+                    at = ([2, 4, 6, 8] if xform else []) + [10 + 3 * i for i in range(NITEM)]  # scale / shift first, then the items: 10, 13, ..., 40
                 for m, ld in zip(at, loads):
                     extra.setdefault(m, []).append(ld)
-                extra.setdefault(42, []).extend(halo_advance())
+                extra.setdefault(56 if CFG == 1 else 42, []).extend(halo_advance())
             if tap == 1:
-                extra.setdefault(45, []).insert(0, need(("H", n + 1)))
+                extra.setdefault(23 if CFG == 1 else 45, []).insert(0, need(("H", n + 1)))
             if tap == 8:  # the slots change roles: kk1 window base behind its last reads, write base behind the last store, kk0 base in front of the pre-read
-                extra.setdefault(16, []).append(I("v_add_s", f"v_add_u32 v{RXB}, s77, v{RXB}", dst=RXB, s=77))
-                extra.setdefault(32, []).append(I("v_subrev_s", f"v_subrev_u32 v{HW}, s77, v{HW}", dst=HW, s=77))
-                extra.setdefault(62, []).append(I("v_add_s", f"v_add_u32 v{RXA}, s77, v{RXA}", dst=RXA, s=77))
-                extra.setdefault(127, []).append(I("s_neg", "s_sub_u32 s77, 0, s77", dst=77))
-        dma_on = not (last and tap >= 7)
+                q = (6, 16, 31, 63) if CFG == 1 else (16, 32, 62, 127)
+                extra.setdefault(q[0], []).append(I("v_add_s", f"v_add_u32 v{RXB}, s77, v{RXB}", dst=RXB, s=77))
+                extra.setdefault(q[1], []).append(I("v_subrev_s", f"v_subrev_u32 v{HW}, s77, v{HW}", dst=HW, s=77))
+                extra.setdefault(q[2], []).append(I("v_add_s", f"v_add_u32 v{RXA}, s77, v{RXA}", dst=RXA, s=77))
+                extra.setdefault(q[3], []).append(I("s_neg", "s_sub_u32 s77, 0, s77", dst=77))
+        dma_on = not (last and tap >= (6 if CFG == 1 else 7))
         next_on = not (last and tap == 8)
         out.extend(ktile(tap, 9 * n + tap, dma_on, next_on, extra, drain=last and tap == 8))
     return out
@@ -249,9 +323,9 @@ def prologue(xform):
         P.append(I("s_mov", f"s_mov_b32 s{d}, {s}", dst=d, src=s))
     P.extend(halo_loads(xform, ("H", 0)))
     P.extend(halo_advance())
-    for t in range(2):
-        for g in range(8):
-            a, b = wdma(g, ("W", t))
+    for t in range(3 if CFG == 1 else 2):
+        for g in range(4 if CFG == 1 else 8):
+            a, b = wdma(g, ("W", t), t)
             P.extend([a, I("nop", "s_nop 0"), b])
         P.extend(w_advance(t + 1))
     for a in range(256):
@@ -263,8 +337,9 @@ def prologue(xform):
     P.append(need(("W", 0)))
     P.append(wait(lgkm=0))
     P.append(BARRIER())
-    P.append(I("v_xor", f"v_xor_b32 v{RW[1]}, {W_TOG:#x}, v{RW[1]}", dst=RW[1], imm=W_TOG))
-    for k in range(8):
+    if CFG == 0:
+        P.append(I("v_xor", f"v_xor_b32 v{RW[1]}, {W_TOG:#x}, v{RW[1]}", dst=RW[1], imm=W_TOG))
+    for k in range(MFX):
         P.append(ds_read(XF[0] + 4 * k, RXA, xoff(0, k, 0)))
     for j in range(8):
         P.append(ds_read(WF[0] + 4 * j, RW[0], j * 2048))
@@ -296,7 +371,9 @@ def set_waits(seq, counts):
             ins.text = f"s_waitcnt vmcnt({c})"
 
 
-def program(xform=True):
+def program(xform=True, cfg=0):
+    global CFG, MFX
+    CFG, MFX = cfg, (4 if cfg == 1 else 8)
     pro = prologue(xform)
     set_waits(pro, resolve(pro, []))
     # the loop body serves its first iteration (behind the prologue) and every later one (behind itself): the stricter count of the two
@@ -313,7 +390,7 @@ def program(xform=True):
     P.append(I("cbranch_scc1", "s_cbranch_scc1 20b", target="LOOP"))
     P.extend(last)
     n = 0
-    for mfi in range(8):  # accumulator row 7 (the other seven left under the last K-tile's MFMAs)
+    for mfi in range(MFX):  # accumulator row 7 (the other seven left under the last K-tile's MFMAs)
         P.extend(drain_tile(7, mfi, n))
         n += 1
     P.append(wait(lgkm=0))
@@ -326,13 +403,15 @@ CLOBBERS = [f"v{i}" for i in range(20, 26)] + ["v28", "v30"] + [f"v{i}" for i in
 
 def emit(csrc):
     progs = {}
-    for xform, name in ((True, "x"), (False, "p")):
-        P = program(xform)
-        progs[xform] = P
+    for xform, cfg, name in ((True, 0, "x"), (False, 0, "p"), (True, 1, "x128"), (False, 1, "p128")):
+        P = program(xform, cfg)
+        progs[(xform, cfg)] = P
+        if cfg == 0:
+            progs[xform] = P
         n_mfma = sum(1 for i in P if i.op == "mfma")
         with open(os.path.join(csrc, f"conv256v4_asm_{name}.inc"), "w") as f:
             f.write("// GENERATED by scripts/gen_conv256v4.py -- do not edit; the CPU emulator in that script checks this instruction list.\n")
-            f.write(f"// {'GroupNorm-apply + SiLU on the way into the halo' if xform else 'plain input (no transform)'}: {len(P)} instructions, "
+            f.write(f"// {'256' if cfg == 0 else '128'}-channel tiles, {'GroupNorm-apply + SiLU on the way into the halo' if xform else 'plain input (no transform)'}: {len(P)} instructions, "
                     f"{n_mfma} MFMAs; explicit registers: see the script's header.\n")
             f.write("\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n")
     with open(os.path.join(csrc, "conv256v4_clobbers.inc"), "w") as f:
@@ -364,22 +443,23 @@ def t_silu(g):
     return (t * g).astype(np.float32)
 
 
-def run(P, xform, tile, late, order, C=192, HWimg=48, ups=0, seed=0, verbose=False):
-    """one workgroup: pixel tile `tile` = (ty, tx) of an HWimg x HWimg image, output channels 0 .. 255"""
+def run(P, xform, tile, late, order, C=192, HWimg=48, ups=0, seed=0, verbose=False, cfg=0):
+    """one workgroup: pixel tile `tile` = (ty, tx) of an HWimg x HWimg image, output channels 0 .. 255 (cfg 1: 0 .. 127)"""
     rng = np.random.default_rng(seed)
     nch = C // 64
     ldw = 9 * C + 8
     Hs = HWimg >> ups
+    NO = 128 if cfg == 1 else 256
     x = bf16_to_f32(bf16_round(rng.standard_normal((Hs, Hs, C)).astype(np.float32)))
-    Wf = bf16_to_f32(bf16_round(rng.standard_normal((256, ldw)).astype(np.float32) * 0.05))
-    bias = bf16_to_f32(bf16_round(rng.standard_normal(256).astype(np.float32)))
+    Wf = bf16_to_f32(bf16_round(rng.standard_normal((NO, ldw)).astype(np.float32) * 0.05))
+    bias = bf16_to_f32(bf16_round(rng.standard_normal(NO).astype(np.float32)))
     gss = np.stack([rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.3]).astype(np.float32)
     gl = {"X": np.frombuffer(bf16_round(x).astype(np.uint16).tobytes(), np.uint8),
           "W": np.frombuffer(bf16_round(Wf).astype(np.uint16).tobytes(), np.uint8),
           "G": np.frombuffer(gss.tobytes(), np.uint8)}
     nrec = {"X": gl["X"].size, "G": gl["G"].size}
     lds = np.zeros(160 * 1024, np.uint8)
-    lds[BIAS_LDS:BIAS_LDS + 1024] = np.frombuffer(bias.astype(np.float32).tobytes(), np.uint8)
+    lds[BIAS_LDS:BIAS_LDS + 4 * NO] = np.frombuffer(bias.astype(np.float32).tobytes(), np.uint8)
     labels = {ins.name: i for i, ins in enumerate(P) if ins.op == "label"}
     lane = np.arange(64)
     l15, q = lane & 15, lane >> 4
@@ -403,17 +483,24 @@ def run(P, xform, tile, late, order, C=192, HWimg=48, ups=0, seed=0, verbose=Fal
             wv.V[HO + i] = np.where(ok, off, 0x80000000).astype(np.uint32)
             okbits |= ok.astype(np.uint32) << i
         wv.V[HMASK] = okbits
-        for g in range(8):
-            hh, j, u = g & 1, (g >> 1) & 1, g >> 2
-            row = hh * 128 + (w * 2 + u) * 16 + j * 8 + srow
-            chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j)
-            wv.V[WP + g] = (row * ldw + chunk * 8) * 2
-        lanex = (wm * 8 * 18 + l15) * H_ROWB + q * 16
+        if cfg == 1:
+            wm, wn2 = w, 0
+            for g in range(4):
+                row = (w * 4 + g) * 8 + srow
+                chunk = (lane & 7) ^ ((row >> 1) & 7)
+                wv.V[WP + g] = (row * ldw + chunk * 8) * 2
+        else:
+            for g in range(8):
+                hh, j, u = g & 1, (g >> 1) & 1, g >> 2
+                row = hh * 128 + (w * 2 + u) * 16 + j * 8 + srow
+                chunk = (lane & 7) ^ (srow >> 1) ^ (4 * j)
+                wv.V[WP + g] = (row * ldw + chunk * 8) * 2
+        lanex = (wm * MFX * 18 + l15) * H_ROWB + q * 16
         wv.V[IN_RX] = lanex
         for kk in range(2):
             wv.V[IN_RW + kk] = W_BASE + wn2 * 16384 + l15 * 128 + (((kk * 4 + q) ^ (l15 >> 1)) << 4)
         c = (l15 >> 2) & 3
-        d0 = (wm * 4 + 2 * wn2) * 16384 + l15 * 64 + (q & 1) * 8 + ((((q >> 1)) ^ c) << 4)
+        d0 = ((2 * w) if cfg == 1 else (wm * 4 + 2 * wn2)) * 16384 + l15 * 64 + (q & 1) * 8 + ((((q >> 1)) ^ c) << 4)
         wv.V[IN_DR] = d0
         wv.V[IN_DR + 1] = d0 ^ 32
         wv.V[GV[0]] = c8 * 32
@@ -600,23 +687,24 @@ def run(P, xform, tile, late, order, C=192, HWimg=48, ups=0, seed=0, verbose=Fal
         full = bf16_to_f32(bf16_round(t_silu(g)))
     pad = np.zeros((HWimg + 2, HWimg + 2, C), np.float32)
     pad[1:-1, 1:-1] = full
-    ref = np.zeros((16, 16, 256), np.float64)
+    ref = np.zeros((16, 16, NO), np.float64)
     for tap in range(9):
         dy, dx = divmod(tap, 3)
         win = pad[ty * 16 + dy: ty * 16 + dy + 16, tx * 16 + dx: tx * 16 + dx + 16].astype(np.float64)
         ref += win @ Wf[:, tap * C:(tap + 1) * C].astype(np.float64).T
     ref += bias[None, None, :]
-    got = np.zeros((256, 256), np.float32)
+    got = np.zeros((256, NO), np.float32)
     for vw in range(8):
-        wm, wn = vw >> 2, vw & 3
+        wm, wn = (vw >> 1, vw & 1) if cfg == 1 else (vw >> 2, vw & 3)  # cfg 1: wave w owns regions 2 w (columns 0-63) and 2 w + 1, 64 rows each
+        rows = 64 if cfg == 1 else 128
         for ni in range(2):
             reg0 = vw * 16384 + ni * 8192
-            for row in range(128):
+            for row in range(rows):
                 for ch in range(4):
                     a = reg0 + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4)
                     vals = lds[a:a + 16].view(np.uint16).astype(np.uint32)
-                    got[wm * 128 + row, wn * 64 + ni * 32 + ch * 8: wn * 64 + ni * 32 + ch * 8 + 8] = bf16_to_f32(vals)
-    got = got.reshape(16, 16, 256)  # row = pixel row * 16 + x
+                    got[wm * rows + row, wn * 64 + ni * 32 + ch * 8: wn * 64 + ni * 32 + ch * 8 + 8] = bf16_to_f32(vals)
+    got = got.reshape(16, 16, NO)  # row = pixel row * 16 + x
     err = np.abs(got - ref) / (np.abs(ref) + 1.0)
     ok = float(err.max()) < 1.2e-2
     if verbose or not ok:
@@ -634,11 +722,13 @@ if __name__ == "__main__":
     print(f"wrote conv256v4_asm_x.inc ({len(progs[True])} instructions), conv256v4_asm_p.inc ({len(progs[False])}) under {csrc}")
     if "--check" in sys.argv:
         allok = True
-        for xform in (True, False):
-            for tile, C, ups in (((0, 0), 128, 0), ((1, 1), 192, 0), ((2, 1), 192, 1 if not xform else 0)):
-                for late in (True, False):
-                    for order in (0, 1):
-                        allok &= run(progs[xform], xform, tile, late, order, C=C, ups=ups, seed=C + tile[0], verbose="-v" in sys.argv)
-            print(f"xform {xform}: {'ok' if allok else 'FAILED'}", flush=True)
+        for cfg in (0, 1):
+            for xform in (True, False):
+                for tile, C, ups in (((0, 0), 128, 0), ((1, 1), 192, 0), ((2, 1), 192, 1 if not xform else 0)):
+                    for late in (True, False):
+                        for order in (0, 1):
+                            program(xform, cfg)  # (sets the module's tile form for the emulator's geometry)
+                            allok &= run(progs[(xform, cfg)], xform, tile, late, order, C=C, ups=ups, seed=C + tile[0], verbose="-v" in sys.argv, cfg=cfg)
+                print(f"cfg {cfg} xform {xform}: {'ok' if allok else 'FAILED'}", flush=True)
         print("ALL OK" if allok else "FAILED")
         sys.exit(0 if allok else 1)

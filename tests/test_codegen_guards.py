@@ -104,13 +104,13 @@ def test_conv256v4_asm_bodies_are_the_generators_and_pass_the_emulator():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import gen_conv256v4 as gen
-    for xform, name in ((True, "x"), (False, "p")):
-        P = gen.program(xform)
+    for xform, cfg, name in ((True, 0, "x"), (False, 0, "p"), (True, 1, "x128"), (False, 1, "p128")):  # cfg 1: the 128-channel tile form
+        P = gen.program(xform, cfg)
         text = "\n".join('    "' + ins.text + '\\n"' for ins in P) + "\n"
         committed = open(os.path.join(ROOT, "diffusionkit_amd", "csrc", f"conv256v4_asm_{name}.inc")).read()
         assert committed.split("\n", 2)[2] == text, f"conv256v4_asm_{name}.inc is stale: run python scripts/gen_conv256v4.py"
         for late in (True, False):
-            assert gen.run(P, xform, (0, 0), late, int(late), C=128, HWimg=32, seed=5), (xform, late)
+            assert gen.run(P, xform, (0, 0), late, int(late), C=128, HWimg=32, seed=5, cfg=cfg), (xform, cfg, late)
     P = gen.program(True)
     halo_waits = [i for i in P if i.op == "wait" and "need" in i.kw and i.need[0] == "H"]
     assert len(halo_waits) >= 2  # prologue + loop body

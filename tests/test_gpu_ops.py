@@ -705,7 +705,10 @@ def test_conv3x3_gn_halo(dev, B, H, W, C, O, res, sc, gn):
                                                    (1, 48, 48, 256, 512, False, True, False),   # an inner tile, two column tiles, four chunks
                                                    (1, 32, 32, 512, 256, True, True, False),    # eight chunks
                                                    (2, 32, 48, 128, 256, False, False, True),   # plain input through the nearest-x2 view
-                                                   (1, 64, 32, 256, 256, True, False, False)])  # plain input, residual
+                                                   (1, 64, 32, 256, 256, True, False, False),   # plain input, residual
+                                                   (2, 32, 48, 128, 128, True, True, False),    # 128-channel tiles (waves 4 x 1, three-slot weight ring)
+                                                   (1, 48, 48, 256, 128, False, True, False),   # ... four chunks, an inner tile
+                                                   (1, 32, 32, 256, 128, False, False, True)])  # ... plain input through the nearest-x2 view
 def test_conv256v4_equals_conv_halo(dev, B, H, W, C, O, res, gn, ups):
     """conv256v4.hip (one wave per SIMD, 16 x 16 pixels x 256 channels per workgroup, asm body: scripts/gen_conv256v4.py) against conv_halo.hip
     on the same inputs: same products, same chunk-major fp32 order, same rounding points (GroupNorm-apply -> bf16 -> SiLU -> bf16 on the way
