@@ -163,6 +163,8 @@ def spawn_ranks(n):
 
 WORKLOAD_NAMES = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-dev-1024": "FLUX.1-dev 1024x1024 50-step",
                   "sd3-medium-1024": "SD3-medium 1024x1024 50-step CFG 5.0", "sd35-large-1024": "SD3.5-large 1024x1024 50-step CFG 5.0",
+                  "flux-schnell-512": "FLUX.1-schnell 512x512 4-step (the reference CLI's default resolution)",
+                  "sd3-medium-512": "SD3-medium 512x512 50-step CFG 5.0 (the reference CLI's default resolution)",
                   "tiny": "tiny"}
 
 
@@ -185,6 +187,13 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
     if workload == "flux-schnell-1024":
         cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (128, 128), 4, 0.0, 1.0, 256, 1
+    elif workload == "flux-schnell-512":
+        # the resolution the reference's CLI defaults to (mlx/scripts/generate_images.py:15-30): latent 64 x 64 = 1024 image tokens, S = 1280
+        cfg, vcfg, cls, mv = FLUX_SCHNELL, VAEDecoderConfig(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (64, 64), 4, 0.0, 1.0, 256, 1
+    elif workload == "sd3-medium-512":
+        cfg, vcfg, cls, mv = SD3_2b, VAEDecoderConfig(), DiffusionPipeline, "argmaxinc/mlx-stable-diffusion-3-medium"
+        latent, num_steps, cfg_weight, shift, S_t, rows = (64, 64), 50, 5.0, 3.0, 589, 2
     elif workload == "flux-dev-1024":
         # BASELINE configs[3] shape: 50 steps, 512 text tokens; like the reference (quirk Q7) FLUX.1-dev runs without its guidance
         # embedding unless --guidance-embed
@@ -461,7 +470,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed images per rank")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "sd35-large-1024", "flux-dev-1024", "tiny"])
+    ap.add_argument("--workload", default="flux-schnell-1024", choices=["flux-schnell-1024", "sd3-medium-1024", "sd35-large-1024", "flux-dev-1024", "flux-schnell-512", "sd3-medium-512", "tiny"])
     ap.add_argument("--batch", default="1",
                     help="images per rank and step, denoised in one batched step loop (FLUX workloads).  Default 1 = BASELINE configs[1] "
                          "per GPU.  BASELINE configs[4] (FLUX.1-schnell, batch 64 sharded over 8 GPUs) is `--gpus 8 --batch 8`; "
@@ -519,17 +528,22 @@ def main():
     other = None
     if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune:
         other = {}
-        for key, (wl, fp8, n_img) in {"sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2),
-                                     "flux-dev-1024 fp8 (BASELINE configs[3]; precision policy: first 12 double blocks bf16, >= 35 dB per step)": ("flux-dev-1024", "quality", 2),
-                                     "flux-dev-1024 fp8, every block Linear in fp8 (32 dB per step)": ("flux-dev-1024", "speed", 1),
-                                     "sd35-large-1024 (the reference's third model family, mlx/config.py:72-74)": ("sd35-large-1024", False, 1)}.items():
-            r = run_workload(ctx, wl, bool(fp8), 1, n_img, 1, want_roofline=not args.no_roofline, max_replay=1, fp8_policy=fp8 or "quality")
+        for key, (wl, fp8, n_img, b_leg) in {
+                "sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2, 1),
+                "flux-dev-1024 fp8 (BASELINE configs[3]; precision policy: first 12 double blocks bf16, >= 35 dB per step)": ("flux-dev-1024", "quality", 2, 1),
+                "flux-dev-1024 fp8, every block Linear in fp8 (32 dB per step)": ("flux-dev-1024", "speed", 1, 1),
+                "sd35-large-1024 (the reference's third model family, mlx/config.py:72-74)": ("sd35-large-1024", False, 1, 1),
+                # round 6: the resolution the reference's CLI defaults to, and the per-GPU shape between configs[1] and configs[4]
+                "flux-schnell-512 (the reference CLI's default resolution, generate_images.py:15-30)": ("flux-schnell-512", False, 8, 1),
+                "sd3-medium-512 (the reference CLI's default resolution)": ("sd3-medium-512", False, 2, 1),
+                "flux-schnell-1024 batch 4 (four images per step loop on one GPU)": ("flux-schnell-1024", False, 2, 4)}.items():
+            r = run_workload(ctx, wl, bool(fp8), b_leg, n_img, 1, want_roofline=not args.no_roofline, max_replay=1, fp8_policy=fp8 or "quality")
             rf = r["roofline"] or {}
             other[key] = {"metric": f"images/sec {WORKLOAD_NAMES[wl]}", "value": r["value"], "unit": "images/s", "steps": n_img, "warmup": 1,
                           "ms_per_step": r["ms_per_step"], "denoise_ms_per_step": r["denoise_ms_per_step"], "vae_decode_ms": r["vae_decode_ms"],
                           "dtype": r["dtype"], "workload": r["workload"], "algorithmic_tflop_per_image": r["algorithmic_tflop_per_image"],
                           "mfma_roofline_frac_whole_path": r["mfma_roofline_frac_whole_path"],
-                          "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "attention", "conv", "bf16_gemm") if k in rf}}
+                          "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "gemm_ms_per_image", "attention", "conv", "bf16_gemm") if k in rf}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":

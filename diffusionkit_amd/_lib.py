@@ -186,23 +186,38 @@ def load() -> C.CDLL:
     return lib
 
 
-_attn_ws = {}
+_attn_ws = {}        # (host thread, device index) -> buffer (kept alive while the library may point at it)
+_attn_ws_device = {}  # host thread -> device index whose buffer the library's thread-local pointer holds right now
 
 
 def ensure_attention_workspace(device) -> None:
     """Hand the library its attention workspace for the calling host thread (dk_attention_set_workspace: the partial results of the
-    key-split workgroups of csrc/attention5.hip), once per thread and device.  Optional for correctness: without it no launch is split."""
+    key-split workgroups of csrc/attention5.hip).  The library keeps ONE pointer per host thread, so the pointer is installed again whenever
+    the thread moves to another device (cuda:0 -> cuda:1 -> cuda:0 must not leave device-1 memory behind device-0 launches).
+    Engines carry their own region (dk_mmdit_* install it for the duration of a call); this one serves the stand-alone ops.
+    Optional for correctness: without it no launch is split."""
     import threading
 
     import torch
-    key = (threading.get_ident(), torch.device(device).index or 0)
-    if key in _attn_ws:
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    tid = threading.get_ident()
+    if _attn_ws_device.get(tid) == index:
         return
     lib = load()
     n = int(lib.dk_attention_workspace_bytes())
-    buf = torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+    buf = _attn_ws.get((tid, index))
+    if buf is None:
+        buf = _attn_ws[(tid, index)] = torch.empty(max(n, 256), dtype=torch.uint8, device=torch.device("cuda", index))
     check(lib.dk_attention_set_workspace(buf.data_ptr(), n), "dk_attention_set_workspace")
-    _attn_ws[key] = buf
+    _attn_ws_device[tid] = index
+
+
+def forget_attention_workspace() -> None:
+    """The calling thread's pointer was overwritten from outside (ops.attention(workspace=...), lab): the next ensure_attention_workspace
+    installs the regular buffer again.  Other threads' entries stay -- their native thread-locals still point at their buffers."""
+    import threading
+    _attn_ws_device.pop(threading.get_ident(), None)
 
 
 def check(rc: int, what: str = "") -> None:

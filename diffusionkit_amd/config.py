@@ -131,8 +131,21 @@ def fp8_config(cfg: MMDiTConfig, policy: str = "quality") -> MMDiTConfig:
     bf16 Linears (>= 35 dB per step, SURVEY.md section 8c iii); "speed": every block Linear in fp8 (31.6 - 32.5 dB per step)."""
     if policy not in ("quality", "speed"):
         raise ValueError(f"unknown fp8 policy {policy!r} (quality | speed)")
+    # (ADVICE r5: reject here what dk_mmdit_create would only reject later -- the fp8 kernels are FLUX geometry: head_dim 128, width a multiple of 256)
+    if cfg.head_dim != 128 or cfg.hidden_size % 256 != 0:
+        raise ValueError(f"fp8_config: the fp8 path needs head_dim 128 and hidden_size % 256 == 0 (got {cfg.head_dim}, {cfg.hidden_size})")
     n = min(FLUX_FP8_QUALITY_BLOCKS, cfg.depth_multimodal) if policy == "quality" else 0
-    return replace(cfg, weight_dtype="fp8_e4m3", fp8_bf16_double_blocks=n)
+    out = replace(cfg, weight_dtype="fp8_e4m3", fp8_bf16_double_blocks=n)
+    validate_fp8_policy(out)
+    return out
+
+
+def validate_fp8_policy(cfg: MMDiTConfig) -> None:
+    """0 <= fp8_bf16_double_blocks <= depth_multimodal (the C engine and weights.pack_mmdit clamp independently: a value outside the range
+    would only surface as a missing-tensor error)."""
+    n = cfg.fp8_bf16_double_blocks
+    if not (0 <= n <= cfg.depth_multimodal):
+        raise ValueError(f"fp8_bf16_double_blocks = {n}: must lie in [0, depth_multimodal = {cfg.depth_multimodal}]")
 
 
 def tiny_flux(depth_multimodal: int = 2, depth_unified: int = 2, heads: int = 2,

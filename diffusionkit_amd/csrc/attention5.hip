@@ -304,14 +304,7 @@ int dk_launch_attention5(const AttnParams& p_in, hipStream_t stream) {
   AttnParams p = p_in;
   const bool qfuse = p.qn_a != nullptr || p.q_rope != nullptr;
   if (qfuse) DK_REQUIRE(p.qn_a == nullptr || p.qn_b != nullptr, "qn_b missing (pass qn_a twice for one weight)");
-  static DkDeviceOnce cu_once;
-  static int n_cu = 256;
-  if (cu_once.first()) {
-    int dev = 0;
-    DK_CHECK_HIP(hipGetDevice(&dev));
-    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    cu_once.mark();
-  }
+  const int n_cu = dk_device_cu_count();
   // One workgroup per CU: a launch of nb blocks runs in ceil(nb / n_cu) rounds, the last one with nb % n_cu blocks.  Those blocks are split
   // into s key ranges each (every range a multiple of four tiles, at least twelve) when that shortens the last round: it then takes
   // ceil(tail * s / n_cu) / s of a block's time.  The partial results go through the workspace and dk_attn5_merge_kernel.

@@ -160,3 +160,17 @@ struct DkDeviceOnce {
     if (dev >= 0) done.fetch_or(1ull << dev, std::memory_order_release);
   }
 };
+
+// Compute units of the CURRENT device, cached per device (the kernel choosers, the pair test and the launchers must agree on one
+// number; a single static shared by all devices, or a literal 256, lets the chooser's tile height and the launcher's disagree on another part).
+// Without a usable device (CPU-side symbol checks) it answers 256, the MI355X's count.
+inline int dk_device_cu_count() {
+  static std::atomic<int> cache[64];
+  const int dev = DkDeviceOnce::device();
+  if (dev < 0) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  cache[dev].store(n, std::memory_order_relaxed);
+  return n;
+}

@@ -436,6 +436,8 @@ struct dk_mmdit {
   bool ctx_ready = false;
   int ldh = 0, ldcat = 0;  // row pitch of HID / CAT (dk_weight_pitch of r*h / (1+r)*h at carve time; fc2 / linear2 weights use the same)
   void* GWS = nullptr;  // GEMM split workspace (fp32 slabs + flags), dk_gemm_split_workspace_bytes()
+  void* AWS = nullptr;  // attention5.hip's key-split partial results of THIS engine's launches (dk_attention_workspace_bytes(); D = 128 only)
+  size_t AWS_bytes = 0;
   bf16_t *temb, *t1, *tvec, *y1, *yvec, *vec;
   float *rope, *tdev;
   // guidance embedding (cfg.guidance_embed): MLPEmbedder weights, the value set by dk_mmdit_set_guidance, scratch rows
@@ -658,6 +660,10 @@ static size_t mmdit_carve(dk_mmdit* m, Carver& c, int B, int Hl, int Wl, int S_t
   m->rope = (float*)c.take(m->cfg.use_rope ? (size_t)S * m->D() * 4 : 0);
   m->tdev = (float*)c.take((size_t)n_t * 4);
   m->GWS = c.take(dk_gemm_split_workspace_bytes());
+  // this engine's own region for the key-split jobs of attention5.hip (two engines, or an engine and ops.attention, driven from one
+  // host thread on different streams must not share the partial results of their split launches)
+  m->AWS_bytes = m->D() == 128 ? dk_attention_workspace_bytes() : 0;
+  m->AWS = c.take(m->AWS_bytes);
   return c.off;
 }
 
@@ -947,9 +953,18 @@ static int mmdit_blocks(dk_mmdit* m, const bf16_t* mod_step, int first, int coun
   return 0;
 }
 
-struct MmditCallScope {  // an engine call's GEMM splits go through THAT engine's region; the caller's setting comes back
+struct AttnWsScope {  // an engine call's attention launches split through that engine's region; the host thread's own setting comes back
+  void* prev;
+  size_t prev_bytes;
+  AttnWsScope(void* ws, size_t bytes) : prev(dk_get_attention_workspace()), prev_bytes(dk_get_attention_workspace_bytes()) {
+    dk_set_attention_workspace(ws, bytes);  // (an engine without a region -- D = 64 -- runs unsplit: never the thread's buffer on another engine's stream)
+  }
+  ~AttnWsScope() { dk_set_attention_workspace(prev, prev_bytes); }
+};
+struct MmditCallScope {  // an engine call's GEMM and attention splits go through THAT engine's regions; the caller's settings come back
   LinearWsScope lin;
-  explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS) {}
+  AttnWsScope att;
+  explicit MmditCallScope(dk_mmdit* m) : lin(m->GWS), att(m->AWS, m->AWS_bytes) {}
 };
 
 // The transformer blocks [first, first + count) of the global order (double blocks 0 .. depth_multimodal - 1, then single blocks)

@@ -247,17 +247,17 @@ static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   // is slow (the lab's 1178 x 6144 x 1536 text fc1: 80 us here against 49 there) and its fixed cost per tile ~ 1 us higher (SD3-medium in the
   // model: every eligible launch 22.0 against 21.5 ms per step, whole-tile launches only 21.2; profiles/r05_gemm_v4_in_model.log).
   // ("gemm_v4" 2: lab, no such restriction)
-  const int mf = dk_gemm256v4_pick_mf(a, b, 256), bm = 32 * mf;
+  const int n_cu = dk_device_cu_count();
+  const int mf = dk_gemm256v4_pick_mf(a, b, n_cu), bm = 32 * mf;
   const bool uniform = dk_gemm256v4_uniform_tiles(a, bm) && (b == nullptr || dk_gemm256v4_uniform_tiles(*b, bm));
-  const bool ragged = a.M % bm != 0 || (b != nullptr && b->M % bm != 0);
-  (void)ragged;
   // (K < 2048: the image stream's fc1 of SD3 alone on this kernel measured +1.1 % per step on one box and -0.9 % on another: short reductions stay
   //  on gemm256v3.hip)
   if ((!uniform || a.K < 2048) && g_dk_v4_auto != 2) return false;
   long tiles = (long)((a.M + bm - 1) / bm) * (a.N / 256);
   if (b) tiles += (long)((b->M + bm - 1) / bm) * (b->N / 256);
-  const long frac = tiles % 256;
-  return tiles <= 256 || tiles >= 2048 || frac == 0 || frac > 144;
+  // (the rounds test in units of the device's CUs: the constants were fitted on 256 CUs -- a last round more than 56 % full, or 8 rounds and more)
+  const long frac = tiles % n_cu;
+  return tiles <= n_cu || tiles >= 8L * n_cu || frac == 0 || frac * 16 > 9L * n_cu;
 }
 
 int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
@@ -350,9 +350,10 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
     const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= 32;
     // (gemm256v4.hip: the same test at ITS tile height -- with 224-row tiles the image + text fc1 of FLUX is 912 + 96 tiles: both 4 rounds)
     if (dk_gemm256v4_eligible(a) && dk_gemm256v4_eligible(b)) {
-      const int bm4 = 32 * dk_gemm256v4_pick_mf(a, &b, 256);
+      const long n_cu = dk_device_cu_count();
+      const int bm4 = 32 * dk_gemm256v4_pick_mf(a, &b, (int)n_cu);
       const long ta4 = (long)((a.M + bm4 - 1) / bm4) * (a.N / 256), tb4 = (long)((b.M + bm4 - 1) / bm4) * (b.N / 256);
-      if ((ta4 + 255) / 256 == (ta4 + tb4 + 255) / 256 && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
+      if ((ta4 + n_cu - 1) / n_cu == (ta4 + tb4 + n_cu - 1) / n_cu && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
     }
     if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);
   }

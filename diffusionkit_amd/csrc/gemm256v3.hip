@@ -915,17 +915,14 @@ static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
 // `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*tiles_a*/, int tiles_b_in, hipStream_t stream) {
   static DkDeviceOnce attr_once;
-  static int n_cu = 0;
   if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0;
-    DK_CHECK_HIP(hipGetDevice(&dev));
-    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_once.mark();
   }
+  const int n_cu = dk_device_cu_count();
   const bool two = tiles_b_in > 0;
   const int mf = pick_mf(p, two ? &pb : nullptr, n_cu);
   const int bm = 32 * mf;

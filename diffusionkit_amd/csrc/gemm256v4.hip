@@ -475,15 +475,12 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
                "grouped GEMM: N, K, epilogue must match");
   }
   static DkDeviceOnce attr_once;
-  static int n_cu = 256;
   if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
-    int dev = 0;
-    DK_CHECK_HIP(hipGetDevice(&dev));
-    DK_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_once.mark();
   }
+  const int n_cu = dk_device_cu_count();
   const int mf = dk_gemm256v4_pick_mf(p, p2, n_cu);
   const int bm = 32 * mf;
   const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / 256);
@@ -493,7 +490,7 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
   dk_prof_begin(0, work, stream);
   // ... in the lab with warm weights.  Inside the model (weights from HBM) the start skew is flat: 58.78 / 58.81 against 58.86 / 58.94 ms per FLUX
   // step (profiles/r05_gemm_v4_start_skew.log) -- the automatic choice keeps it off; dk_tune_set("gemm_skew", n) turns it on
-  const int skew = tiles_a + tiles_b <= 256 || g_dk_v4_skew < 0 ? 0 : g_dk_v4_skew;
+  const int skew = tiles_a + tiles_b <= n_cu || g_dk_v4_skew < 0 ? 0 : g_dk_v4_skew;
   if (mf == 7)
     hipLaunchKernelGGL(dk_gemm256v4_kernel<7>, dim3(tiles_a + tiles_b), dim3(256), V4_LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, skew);
   else

@@ -67,6 +67,9 @@ class MMDiTEngine:
         if config.weight_dtype not in ("bfloat16", "fp8_e4m3"):
             raise _lib.DkHipError(f"unknown weight_dtype {config.weight_dtype!r} (bfloat16 | fp8_e4m3)")
         c.fp8_linears = int(config.weight_dtype == "fp8_e4m3")
+        if c.fp8_linears:
+            from .config import validate_fp8_policy
+            validate_fp8_policy(config)
         c.fp8_bf16_double_blocks = int(config.fp8_bf16_double_blocks) if c.fp8_linears else 0
         h = C.c_void_p()
         _lib.check(self.lib.dk_mmdit_create(C.byref(c), C.byref(h)), "dk_mmdit_create")

@@ -203,7 +203,7 @@ def attention(qkv: Tensor, H: int, D: int, scale: Optional[float] = None, worksp
     finally:
         if workspace is not None:
             lib.dk_attention_set_workspace(None, 0)
-            _lib._attn_ws.clear()  # (the next call hands the library its regular workspace again)
+            _lib.forget_attention_workspace()  # (this thread's next call hands the library its regular workspace again)
     return out
 
 

@@ -244,6 +244,9 @@ def pack_mmdit(cfg: MMDiTConfig, w: Dict[str, Tensor], device, consume: bool = F
     out: Dict[str, Tensor] = {}
     get = (lambda k: w.pop(k)) if consume else (lambda k: w[k])
 
+    if fp8:
+        from .config import validate_fp8_policy
+        validate_fp8_policy(cfg)
     n_bf = int(getattr(cfg, "fp8_bf16_double_blocks", 0)) if fp8 else 0
     keep_bf16 = tuple(f"multimodal_transformer_blocks.{i}." for i in range(min(n_bf, cfg.depth_multimodal)))  # precision policy
 

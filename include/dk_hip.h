@@ -138,7 +138,10 @@ int dk_attention_bf16(const void* q, const void* k, const void* v, void* out, in
 /* Workspace of the attention launches THIS host thread enqueues (256-byte aligned, dk_attention_workspace_bytes() bytes; NULL: none).
  * The one-wave-per-SIMD D = 128 kernel (attention5.hip) splits the query blocks of a launch's last, partial round of the CUs along the
  * keys and merges the partial results through it.  Optional: without a workspace nothing is split (same results up to the bf16
- * rounding of the partials; FLUX 1024^2, one image: ~10 % longer attention launches). */
+ * rounding of the partials; FLUX 1024^2, one image: ~10 % longer attention launches).  ONE split launch at a time may use a given
+ * workspace: launches that share it must be ordered on one stream.  The pointer is per host thread, not per device -- a thread that
+ * moves to another device installs that device's buffer again.  dk_mmdit_* calls do not use this buffer: every engine carves its own
+ * region from its workspace and installs it for the duration of the call (two engines on two streams never share partial results). */
 size_t dk_attention_workspace_bytes(void);
 int dk_attention_set_workspace(void* workspace, size_t bytes);
 

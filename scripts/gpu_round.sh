@@ -30,9 +30,15 @@ export TMPDIR=/tmp PYTHONUNBUFFERED=1
 : "${BENCH_sd35:=--workload sd35-large-1024 --steps 1 --warmup 1}"
 : "${BENCH_b8:=--batch 8 --steps 3 --warmup 1}"
 : "${BENCH_driver:=--steps 20 --warmup 5}"
+: "${BENCH_f512:=--workload flux-schnell-512 --steps 8 --warmup 2}"
+: "${BENCH_s512:=--workload sd3-medium-512 --steps 2 --warmup 1}"
+: "${BENCH_b4:=--batch 4 --steps 2 --warmup 1}"
 : "${PROF_TAIL:=--no-cpu-baseline --no-roofline --no-other-configs}"
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
 bench_args() { local v="BENCH_$1"; echo "${!v}"; }
+# the tree this box runs: scripts/gpu_call.sh (build container) leaves the commit in .dk_build_stamp; the library's own hash is taken here
+STAMP="tree: $(cat .dk_build_stamp 2>/dev/null || echo 'no .dk_build_stamp'); libdk_hip.so sha256 $(sha256sum diffusionkit_amd/libdk_hip.so 2>/dev/null | cut -c1-16); csrc sha256 $(cat diffusionkit_amd/csrc/*.hip diffusionkit_amd/csrc/*.h diffusionkit_amd/csrc/*.inc 2>/dev/null | sha256sum | cut -c1-16); run tag $TAG"
+echo "$STAMP" > $OUT/stamp.txt
 for ST in $STAGES; do
   KIND=${ST%%:*}; NAME=${ST#*:}; [ "$NAME" = "$ST" ] && NAME=flux
   T0=$(date +%s)
@@ -52,7 +58,7 @@ for ST in $STAGES; do
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof_$NAME -o run -- python $OLDPWD/bench.py --gpus 1 $(bench_args $NAME) $PROF_TAIL > $OLDPWD/$OUT/prof_$NAME.log 2>&1)
       echo "prof $NAME exit $?"
-      { echo "command: rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 $(bench_args $NAME) $PROF_TAIL"; echo;
+      { echo "$STAMP"; echo; echo "command: rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 $(bench_args $NAME) $PROF_TAIL"; echo;
         python scripts/rocpd_summary.py $(find $OUT/prof_$NAME -name "*.db" | head -1) --by-grid; } > $OUT/kernel_stats_$NAME.md 2>&1
       head -n 14 $OUT/kernel_stats_$NAME.md
       rm -rf $OUT/prof_$NAME ;;  # the rocpd database (10+ MiB per run) stays on the box; the summary travels
@@ -64,9 +70,9 @@ for ST in $STAGES; do
         echo "pmc $NAME $TAGC exit $?"
         find $OUT/pmc_$TAGC -name "*kernel_trace.csv" -size +30M -delete
       done
-      python scripts/pmc_traffic.py $OUT > $OUT/pmc_traffic_$NAME.log 2>&1; tail -n 14 $OUT/pmc_traffic_$NAME.log
+      { echo "$STAMP"; python scripts/pmc_traffic.py $OUT; } > $OUT/pmc_traffic_$NAME.log 2>&1; tail -n 14 $OUT/pmc_traffic_$NAME.log
       [ -f $OUT/pmc_gemm_traffic.json ] && mv $OUT/pmc_gemm_traffic.json $OUT/pmc_gemm_traffic_$NAME.json
-      { python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES gemm256; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES dk_attn; } > $OUT/pmc_sq_$NAME.log 2>&1
+      { echo "$STAMP"; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES gemm256; python scripts/pmc_summary.py $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES dk_attn; } > $OUT/pmc_sq_$NAME.log 2>&1
       tail -n 12 $OUT/pmc_sq_$NAME.log
       rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;  # raw CSVs exceed the 64 MiB pull limit
     run)

@@ -40,6 +40,10 @@ Round 5 (VERDICT r4 "Next round" item 2: CLOSED-LOOP runs of the 50-step configu
   flux_dev_10    BASELINE configs[3]'s shape closed loop: 19 + 38 blocks at FLUX width, S_t = 512, a complete 10-step schedule
                  (sigma 1 -> 0) -> the latent after steps 1, 2, 5 (fp16) and 10 (fp32); replayed with bf16 and with fp8 weights
 
+Round 6 (VERDICT r5 "Next round" item 4: configs[3] closed loop at its STATED length):
+  flux_dev_50    the same model, conditioning and start noise over the complete 50-step schedule (fp32 oracle, ~3 h on 5 cores) -> the
+                 latent after steps 1, 2, 5, 10, 20, 30, 40 (fp16) and 50 (fp32); replayed with bf16, the fp8 policy and every block fp8
+
 The fp32 oracle of the FLUX cases and of every round-3 case is the reference's function with fp32 ACTIVATIONS: its timestep
 embedding is still evaluated in config.dtype (mmdit.py:379-389, quirk Q2; bf16 for FLUX, fp16 for SD3) -- ``ref_model`` below.
 Round 2's FLUX fixtures used an oracle with an exact embedding and measured, at 27-32 dB, the distance between two different
@@ -122,6 +126,10 @@ SD3_FULL_LATE = dict(cfg=SD3_2b, seed_w=1234, latent=(128, 128), S_t=589, steps_
 SD3_FULL_50 = dict(SD3_FULL_1024, n_steps=50, keep=(1, 3, 10, 20, 30, 40, 50), seed_vae=4321)
 FLUX_DEV_10 = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=512, steps=10, shift=1.0, noise_seed=0, keep=(1, 2, 5, 10),
                    text_seed=73)
+
+
+# ---- round 6 case: configs[3]'s shape closed loop at its STATED length ---------------------------------------------
+FLUX_DEV_50 = dict(FLUX_DEV_10, steps=50, keep=(1, 2, 5, 10, 20, 30, 40, 50))
 
 
 def forced_inputs(c):
@@ -464,14 +472,14 @@ def flux_dev_10_inputs():
     return text, pooled
 
 
-def make_flux_dev_10():
-    """configs[3]'s shape closed loop: a complete 10-step schedule through denoise_latents (fp32 oracle)"""
-    c = FLUX_DEV_10
+def make_flux_dev_10(c=None, name="flux_dev_10"):
+    """configs[3]'s shape closed loop: a complete 10-step (round 6: 50-step, FLUX_DEV_50) schedule through denoise_latents (fp32 oracle)"""
+    c = c or FLUX_DEV_10
     cfg = c["cfg"]
     w = LazyFloat(synth_mmdit_weights(cfg, seed=c["seed_w"]))
     text, pooled = flux_dev_10_inputs()
     t0 = time.time()
-    trace = ProgressTrace("flux_dev_10", t0)
+    trace = ProgressTrace(name, t0)
     lat = op.denoise_latents(ref_model(cfg, w, Prec()), text, pooled, c["steps"], 0.0, c["latent"], c["noise_seed"], c["shift"], True, Prec(BF),
                              trace=trace)
     out = {"keep": np.asarray(c["keep"]), "latent_fp32": lat.numpy()}
@@ -480,7 +488,7 @@ def make_flux_dev_10():
     return out
 
 
-CASES = {"sd3_full_50": make_sd3_full_50, "sd3_full_50_emu": make_sd3_full_50_emu, "flux_dev_10": make_flux_dev_10, "flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
+CASES = {"flux_dev_50": lambda: make_flux_dev_10(FLUX_DEV_50, "flux_dev_50"), "sd3_full_50": make_sd3_full_50, "sd3_full_50_emu": make_sd3_full_50_emu, "flux_dev_10": make_flux_dev_10, "flux_pair": make_flux_pair, "sd3_512": make_sd3_512, "vae_1024": make_vae_1024, "sd3_1024": lambda: make_forward(SD3_1024, "sd3_1024"),
          "flux_1024": lambda: make_forward(FLUX_1024, "flux_1024"), "flux_full": make_flux_full,
          "flux_full_emu": lambda: make_flux_full(True),
          "flux_dev_512": lambda: make_forward(FLUX_DEV_512, "flux_dev_512"), "sd3_full_1024": make_sd3_full_1024,
