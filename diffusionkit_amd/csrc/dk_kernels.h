@@ -64,6 +64,7 @@ extern int g_dk_v3_mf;     // gemm256v3.hip: wave-tile height in 16-row fragment
 size_t dk_gemm_split_workspace_bytes();
 bool dk_gemm256v3_eligible(const GemmParams& p);  // N % 128 == 0, K % 64 == 0, any M, any row-segment maps
 int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t stream);
+bool dk_gemm256v3_splits_whole_launch(const GemmParams& p, const GemmParams* p2);  // <= half a round of tiles, every tile cut along K (needs p.workspace)
 // gemm256v4.hip: one wave per SIMD, 256 accumulators in AGPRs, hand-scheduled asm body (N % 256 == 0, no conv / K split / half tiles)
 extern int g_dk_v4_auto;  // gemm.hip
 extern int g_dk_v4_skew;  // gemm256v4.hip

@@ -243,6 +243,9 @@ static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   if (g_dk_gemm_mode != 10 && (g_dk_gemm_mode != -1 || g_dk_v4_auto == 0)) return false;
   if (!dk_gemm256v4_eligible(a) || (b != nullptr && !dk_gemm256v4_eligible(*b))) return false;
   if (g_dk_gemm_mode == 10) return true;
+  // Small launches (round 6): at most half a round of tiles, and gemm256v3.hip would cut every one of them along K -- FLUX at the reference CLI's
+  // 512 x 512 default: o_proj / fc2 / linear2 are 60 - 84 tiles on 256 CUs, linear2 229 us on this kernel (profiles/r06_flux_512_kernel_stats_before.md)
+  if (g_dk_v4_auto != 2 && dk_gemm256v3_splits_whole_launch(a, b)) return false;
   // launches with tiles that straddle row segments or short reductions with ragged rows stay on gemm256v3.hip: this kernel's per-row tail path
   // is slow (the lab's 1178 x 6144 x 1536 text fc1: 80 us here against 49 there) and its fixed cost per tile ~ 1 us higher (SD3-medium in the
   // model: every eligible launch 22.0 against 21.5 ms per step, whole-tile launches only 21.2; profiles/r05_gemm_v4_in_model.log).

@@ -899,17 +899,45 @@ int g_dk_v3_mf = -1;
 // the model promises, because a K-tile runs slower the more CUs are busy (the chip is power / fabric bound) -- and on
 // the short-K SD3 shapes the 15 % extra tiles (each with its fixed prologue + tail) cost more than the fuller round gives back.
 // So: 224-row tiles only for long reductions, and only when the model predicts at least 10 %.
-static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu) {
+static long v3_tiles(const GemmParams& p, const GemmParams* p2, int bm) {
+  long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
+  if (p2) tiles += (long)((p2->M + bm - 1) / bm) * ((p2->N + T256 - 1) / T256);
+  return tiles;
+}
+static bool v3_have_ws(const GemmParams& p, const GemmParams* p2) {
+  // (a launch with the fused key QKNorm is never split: a split tile's finisher has no second pass over its row sums)
+  return p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0 &&
+         p.kn_w == nullptr && (p2 == nullptr || p2->kn_w == nullptr);
+}
+static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu, bool have_ws) {
   if (g_dk_v3_mf == 7 || g_dk_v3_mf == 8) return g_dk_v3_mf;
   if (p.K < 2048) return 8;
+  // Small launches (round 6; the reference CLI's 512 x 512 default: FLUX's o_proj / fc2 / linear2 are 60 - 84 tiles for 256 CUs): when both
+  // heights leave at least half the CUs idle the launch is one split "remainder", and what a CU runs is the finisher piece: ks K-tiles of bm rows
+  if (have_ws && v3_tiles(p, p2, 224) * 2 <= n_cu && v3_tiles(p, p2, 256) * 2 <= n_cu) {
+    const int nk = p.K / BK;
+    const SplitPlan s7 = plan_split((int)v3_tiles(p, p2, 224), nk, true, n_cu), s8 = plan_split((int)v3_tiles(p, p2, 256), nk, true, n_cu);
+    return 224L * (s7.n_rem > 0 ? s7.ks : nk) < 256L * (s8.n_rem > 0 ? s8.ks : nk) ? 7 : 8;
+  }
   long cost[2];
   for (int mf = 7; mf <= 8; ++mf) {
     const int bm = 32 * mf;
-    long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
-    if (p2) tiles += (long)((p2->M + bm - 1) / bm) * ((p2->N + T256 - 1) / T256);
-    cost[mf - 7] = ((tiles + n_cu - 1) / n_cu) * bm;
+    cost[mf - 7] = ((v3_tiles(p, p2, bm) + n_cu - 1) / n_cu) * bm;
   }
   return cost[0] * 10 <= cost[1] * 9 ? 7 : 8;
+}
+
+// The whole launch is at most half a round of the CUs and this kernel would cut every tile along K (dk_use_v4 in gemm.hip leaves such
+// launches here: the one-wave-per-SIMD kernel has no K split, and 60 tiles on 256 CUs waste three quarters of the chip)
+bool dk_gemm256v3_splits_whole_launch(const GemmParams& p, const GemmParams* p2) {
+  if (p.conv || !dk_gemm256v3_eligible(p) || (p2 != nullptr && !dk_gemm256v3_eligible(*p2))) return false;
+  const int n_cu = dk_device_cu_count();
+  const bool have_ws = v3_have_ws(p, p2);
+  const int bm = 32 * pick_mf(p, p2, n_cu, have_ws);
+  const long tiles = v3_tiles(p, p2, bm);
+  if (tiles * 2 > n_cu) return false;
+  const SplitPlan pl = plan_split((int)tiles, p.K / BK, have_ws, n_cu);
+  return pl.n_rem > 0 && pl.n_dp == 0;
 }
 
 // `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)
@@ -924,13 +952,11 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   }
   const int n_cu = dk_device_cu_count();
   const bool two = tiles_b_in > 0;
-  const int mf = pick_mf(p, two ? &pb : nullptr, n_cu);
+  const bool have_ws = v3_have_ws(p, two ? &pb : nullptr);
+  const int mf = pick_mf(p, two ? &pb : nullptr, n_cu, have_ws);
   const int bm = 32 * mf;
   const int tiles_a = ((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
   const int tiles_b = two ? ((pb.M + bm - 1) / bm) * ((pb.N + T256 - 1) / T256) : 0;
-  // (a launch with the fused key QKNorm is never split: a split tile's finisher has no second pass over its row sums)
-  const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0 &&
-                       p.kn_w == nullptr && (!two || pb.kn_w == nullptr);
   const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
   SplitArgs sp;
   memset(&sp, 0, sizeof(sp));
