@@ -1074,8 +1074,11 @@ static int mmdit_blocks_bf16(dk_mmdit* m, const bf16_t* mod_step, int first, int
     if (fuse_q() && !(fuse_k(w.kn) && fuse_qg(w.qn, false))) { ap.qn_a = ap.qn_b = w.qn; ap.qn_split = 0; ap.q_rope = c.use_rope ? m->rope : nullptr; }
     DK_TRY(dk_launch_attention(ap, st));
     // x += gate * ([attn | gelu] @ [o_proj | fc2]^T + bias)   (one bias: quirk Q8)
-    DK_TRY(linear_call(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, (1 + r) * h, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
-                       m->X, h, M, 0, st, ldcat));
+    {  // (through linear_params: with this engine's split workspace -- below 1024 x 1024 the launch is a fraction of a round of the CUs and is cut along K)
+      const GemmParams l2 = linear_params(m->CAT, ldcat, M, 0, w.l2_w, w.l2_b, m->X, h, M, 0, M, h, (1 + r) * h, DK_EPI_GATE_RES, mod + 2 * h, S, mod_stride,
+                                          m->X, h, M, 0, ldcat);
+      DK_TRY(dk_launch_gemm(l2, st));
+    }
   }
 
   return 0;

@@ -865,7 +865,7 @@ size_t dk_gemm_split_workspace_bytes() { return (size_t)256 * SLAB_FLOATS * 4 + 
 struct SplitPlan {
   int n_dp, n_rem, S, ks;
 };
-static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
+static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu, bool linear = false) {
   SplitPlan none{tiles, 0, 1, nk};
   if (!have_ws || g_dk_v3_split == 0 || n_cu < 16) return none;
   const int G = n_cu & ~7;
@@ -888,6 +888,10 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu) {
   if (S < 2 || ks < 1 || nk - ks < S - 1 || T * (S - 1) > 256) return none;
   // a K-tile step costs about 1.45 us; splitting costs a slab write + read and a flag round trip per tile
   if (g_dk_v3_split < 0 && (nk - t_steps) * 1.45 < 25.0) return none;
+  // a Linear that is ALL remainder (round 6: FLUX below 1024 x 1024, 60 - 120 tiles): every tile pays S - 1 slab round trips at once, and the few
+  // busy CUs run their K-tiles in ~1 us -- measured break-even at ~66 saved K-tile steps (profiles/r06_gemm_small_m.log: o_proj K = 3072 loses
+  // 16 us with the split, fc2 / linear2 gain 60 - 90)
+  if (g_dk_v3_split < 0 && linear && tiles < G && nk - t_steps < 80) return none;
   return SplitPlan{tiles - T, T, S, ks};
 }
 
@@ -914,10 +918,11 @@ static int pick_mf(const GemmParams& p, const GemmParams* p2, int n_cu, bool hav
   if (p.K < 2048) return 8;
   // Small launches (round 6; the reference CLI's 512 x 512 default: FLUX's o_proj / fc2 / linear2 are 60 - 84 tiles for 256 CUs): when both
   // heights leave at least half the CUs idle the launch is one split "remainder", and what a CU runs is the finisher piece: ks K-tiles of bm rows
-  if (have_ws && v3_tiles(p, p2, 224) * 2 <= n_cu && v3_tiles(p, p2, 256) * 2 <= n_cu) {
+  const long t7 = v3_tiles(p, p2, 224), t8 = v3_tiles(p, p2, 256);
+  if (have_ws && !p.conv && (t7 < t8 ? t7 : t8) * 2 <= n_cu && t7 <= n_cu && t8 <= n_cu) {
     const int nk = p.K / BK;
-    const SplitPlan s7 = plan_split((int)v3_tiles(p, p2, 224), nk, true, n_cu), s8 = plan_split((int)v3_tiles(p, p2, 256), nk, true, n_cu);
-    return 224L * (s7.n_rem > 0 ? s7.ks : nk) < 256L * (s8.n_rem > 0 ? s8.ks : nk) ? 7 : 8;
+    const SplitPlan s7 = plan_split((int)t7, nk, true, n_cu, true), s8 = plan_split((int)t8, nk, true, n_cu, true);
+    if (s7.n_rem > 0 || s8.n_rem > 0) return 224L * (s7.n_rem > 0 ? s7.ks : nk) < 256L * (s8.n_rem > 0 ? s8.ks : nk) ? 7 : 8;
   }
   long cost[2];
   for (int mf = 7; mf <= 8; ++mf) {
@@ -936,7 +941,7 @@ bool dk_gemm256v3_splits_whole_launch(const GemmParams& p, const GemmParams* p2)
   const int bm = 32 * pick_mf(p, p2, n_cu, have_ws);
   const long tiles = v3_tiles(p, p2, bm);
   if (tiles * 2 > n_cu) return false;
-  const SplitPlan pl = plan_split((int)tiles, p.K / BK, have_ws, n_cu);
+  const SplitPlan pl = plan_split((int)tiles, p.K / BK, have_ws, n_cu, true);
   return pl.n_rem > 0 && pl.n_dp == 0;
 }
 
@@ -957,7 +962,7 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   const int bm = 32 * mf;
   const int tiles_a = ((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
   const int tiles_b = two ? ((pb.M + bm - 1) / bm) * ((pb.N + T256 - 1) / T256) : 0;
-  const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu);
+  const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu, !p.conv);
   SplitArgs sp;
   memset(&sp, 0, sizeof(sp));
   sp.n_dp = pl.n_dp; sp.n_rem = pl.n_rem; sp.S = pl.S; sp.ks = pl.ks;

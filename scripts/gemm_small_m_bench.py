@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 lib = _lib.load()
 ncopy = int(os.environ.get("COLD_W", "8"))
 g = torch.Generator(device=dev).manual_seed(0)
-ws = torch.zeros(int(lib.dk_gemm_split_workspace_bytes()), dtype=torch.uint8, device=dev)
+ws = torch.zeros(int(lib.dk_gemm_workspace_bytes()), dtype=torch.uint8, device=dev)
 h = 3072
 shapes = []
 for tag, M in (("512^2", 1280), ("768^2", 2560), ("1024^2", 4352)):
