@@ -376,6 +376,41 @@ def test_gemm_v3_remainder_split(dev, M, N, K, epi, mf):
     assert int(ws[-4096:].sum()) == 0
 
 
+@pytest.mark.parametrize("M,N,K,epi,split", [(1280, 3072, 12288, "gate_res", True),   # FLUX 512 x 512 fc2: 60 tiles of 256 rows, four K ranges each
+                                              (1280, 3072, 15360, "gate_res", True),   # ... linear2
+                                              (2560, 3072, 12288, "bias", True),       # 768 x 768: 120 tiles, two K ranges
+                                              (1280, 3072, 3072, "gate_res", False),   # o_proj: below the break-even, stays whole
+                                              (4352, 3072, 12288, "gate_res", False)])  # 1024 x 1024: a full round, untouched
+def test_gemm_small_launch_is_split_automatically(dev, M, N, K, epi, split):
+    """Round 6 (the reference CLI's 512 x 512 default, generate_images.py:15-30): a block Linear of at most half a round of 256 x 256 tiles is cut
+    along K by the AUTOMATIC choice (gemm.hip: dk_use_v4 -> gemm256v3.hip's split) when the caller hands in the split workspace, as the engines do.
+    Against the fp32 oracle, and against the same launch with the split switched off: bit-identical where the rule leaves the launch whole,
+    equal up to the fp32 summation order where it is cut."""
+    from diffusionkit_amd import ops
+    x, w, b = randn(M, K, seed=60), randn(N, K, seed=61, scale=0.02), randn(N, seed=62, scale=0.1)
+    res, gate = randn(M, N, seed=63), randn(1, N, seed=64)
+    acc = bf16r(x @ w.t() + b)
+    ws = ops.gemm_workspace(dev)
+    if epi == "gate_res":
+        kw, ref = dict(epilogue=ops.DK_EPI_GATE_RES, gate=g(gate, dev), res=g(res, dev), gate_seg_len=M), res + bf16r(gate * acc)
+    else:
+        kw, ref = {}, acc
+    y = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
+    try:
+        ops.tune("gemm_split", 0)
+        y0 = ops.linear(g(x, dev), g(w, dev), g(b, dev), workspace=ws, **kw)
+    finally:
+        ops.tune("gemm_split", -1)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP
+    assert rel_l2(ref, y0.float()) < TOL_SINGLE_OP
+    if split:
+        assert not torch.equal(y0, y), "the launch was expected to be cut along K (other summation order)"
+        assert float((y0.float() != y.float()).float().mean()) < 0.05
+    else:
+        assert torch.equal(y0, y)
+    assert int(ws[-4096:].sum()) == 0  # the flag region is left zero
+
+
 @pytest.mark.parametrize("B,H,W,C,O", [(1, 16, 16, 64, 128), (2, 8, 24, 128, 64), (1, 64, 32, 64, 64)])
 def test_conv3x3_stride2_downsample(dev, B, H, W, C, O):
     """EncoderDecoderBlock2D downsample (vae.py:141-143): pad bottom / right by one, conv k3 s2 p0."""
@@ -494,6 +529,26 @@ def test_attention5_key_split_of_the_last_round(dev, split):
     assert rel_l2(ref, outs[split].float()) < 6e-3
     assert not torch.equal(outs[0], outs[split])  # (the switch does select the split launch: the partials are rounded to bf16)
     assert max_abs(outs[0].float(), outs[split].float()) < 0.02 * float(ref.abs().max()) + 4e-3
+
+
+def test_attention5_batch_consistency(dev):
+    """whether a query block goes through the key-split jobs (bf16-rounded partial results + merge) depends on the launch's last round of
+    the CUs, hence on the batch: FLUX's 24 heads x 4352 tokens are 408 blocks at B = 1 (last round 152 blocks: not split) and 1632 at B = 4 (last
+    round 96 blocks: two key ranges each).  An image's attention output is therefore NOT bit-identical between batch sizes -- pinned here: every
+    image of the batch equals its own single-image launch to the rounding of the partials, and the images the last round does not reach bit for bit."""
+    from diffusionkit_amd import ops
+    B, H, S, D = 4, 24, 4352, 128
+    h = H * D
+    qkv = g(randn(B, S, 3 * h, seed=36), dev)
+    y4 = ops.attention(qkv, H, D)
+    worst, exact = 0.0, 0
+    for i in range(B):
+        y1 = ops.attention(qkv[i:i + 1].contiguous(), H, D)
+        exact += int(torch.equal(y1[0], y4[i]))
+        worst = max(worst, float((y1[0].float() - y4[i].float()).abs().max()))
+    print(f"[attention5] B = 4 against four B = 1 launches: {exact} of 4 images bit-identical, worst |diff| {worst:.3e}")
+    assert exact >= 3  # (the 96 blocks of the last round are the last heads of the last image)
+    assert worst <= 2.0 ** -6  # two bf16 roundings of values of magnitude <= 1 (outputs are convex combinations of N(0, 1) values: |O| < 1)
 
 
 def test_attention5_spiked_key_forces_rescale(dev):
