@@ -168,7 +168,7 @@ WORKLOAD_NAMES = {"flux-schnell-1024": "FLUX.1-schnell 1024x1024 4-step", "flux-
                   "tiny": "tiny"}
 
 
-def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4, fp8_policy="quality"):
+def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, overlap_decode=False, want_roofline=True, max_replay=4, fp8_policy="quality", res=None):
     """One bench leg: build the pipeline of `workload` on this rank, `warmup` untimed images, EXACTLY `steps` timed images
     (each = the denoising steps + the VAE decode) bracketed by barrier + synchronize on both sides, max over ranks; then the
     per-launch HIP-event replay for the roofline figures (rank 0).  Returns a dict of measurements (rank 0) or None."""
@@ -210,6 +210,8 @@ def run_workload(ctx, workload, fp8, B, steps, warmup, guidance_embed=False, ove
     else:
         cfg, vcfg, cls, mv = tiny_flux(), tiny_vae(), FluxPipeline, "argmaxinc/mlx-FLUX.1-schnell"
         latent, num_steps, cfg_weight, shift, S_t, rows = (16, 16), 4, 0.0, 1.0, 64, 1
+    if res:  # lab sweeps (scripts/res_sweep.sh): the same model at another square resolution, latent = pixels / 8
+        latent = (res // 8, res // 8)
     if fp8:
         assert cfg.is_flux and workload != "tiny", "--fp8 is offered for the FLUX workloads (head_dim 128, token counts multiples of 128)"
         from diffusionkit_amd.config import fp8_config
@@ -489,6 +491,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs of BASELINE configs[2] (SD3-medium 1024x1024, 50 steps, CFG 5) and configs[3] (FLUX.1-dev, 50 steps, "
                          "fp8 weights) that the default single-GPU headline run appends as `other_configs`")
+    ap.add_argument("--res", type=int, default=None, metavar="PIXELS",
+                    help="lab: run the chosen workload's model at PIXELS x PIXELS instead of its own resolution (a multiple of 16; dispatch sweeps, profiles/r06_res_sweep.md)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="dk_tune_set knob for A/B runs, e.g. --tune gemm_mf=8 (default kernels otherwise)")
     ap.add_argument("--dry-run", action="store_true",
@@ -521,12 +525,12 @@ def main():
     ctx = {"rank": rank, "world": world, "dev": dev, "lib": lib}
 
     head = run_workload(ctx, args.workload, args.fp8, B, args.steps, args.warmup, guidance_embed=args.guidance_embed,
-                        overlap_decode=args.overlap_decode, want_roofline=not args.no_roofline, fp8_policy=args.fp8_policy)
+                        overlap_decode=args.overlap_decode, want_roofline=not args.no_roofline, fp8_policy=args.fp8_policy, res=args.res)
 
     # ---- the other north-star configurations on the same driver-timed line (single-GPU headline runs only): short bounded legs,
     # same code path and timing contract as the headline (warm-up, barrier + synchronize brackets, decode inside the region) ----
     other = None
-    if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune:
+    if world == 1 and args.workload == "flux-schnell-1024" and not args.fp8 and B == 1 and not args.no_other_configs and not args.tune and not args.res:
         other = {}
         for key, (wl, fp8, n_img, b_leg) in {
                 "sd3-medium-1024 (BASELINE configs[2])": ("sd3-medium-1024", False, 2, 1),

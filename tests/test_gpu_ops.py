@@ -548,7 +548,7 @@ def test_attention5_batch_consistency(dev):
         worst = max(worst, float((y1[0].float() - y4[i].float()).abs().max()))
     print(f"[attention5] B = 4 against four B = 1 launches: {exact} of 4 images bit-identical, worst |diff| {worst:.3e}")
     assert exact >= 3  # (the 96 blocks of the last round are the last heads of the last image)
-    assert worst <= 2.0 ** -6  # two bf16 roundings of values of magnitude <= 1 (outputs are convex combinations of N(0, 1) values: |O| < 1)
+    assert worst <= 4e-3  # measured 9.8e-4: bf16 roundings of the two partial results of values of magnitude < 0.25
 
 
 def test_attention5_spiked_key_forces_rescale(dev):
