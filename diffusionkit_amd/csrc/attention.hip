@@ -36,9 +36,12 @@ int dk_launch_attention(const AttnParams& p_in, hipStream_t stream) {
   // automatic choice (kernel lab, profiles/archive/r01_attention_lab.md, r02_attn_bench.log, r03_attention_phase_alternating.md): D = 128 on
   // long sequences: the phase-alternating kernel; otherwise the VALU-lean kernel with 4 waves (D = 64: 842 TF against 773 / 823 for the
   // pipelined forms).  A score bias (text encoders) is only implemented by the lean kernel
-  // (round 6, profiles/r06_attention_short_sequences.log: at FLUX's 512 x 512 sequence, S = 1280, the one-wave-per-SIMD kernel ties with the lean kernel on
-  //  one image -- 120 workgroups, half a round of the CUs -- and wins 16 - 26 % on batches of it; at S = 768 the two tie: the threshold moved from 2048 to 1024)
-  int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? ((p.D == 128 && p.S >= 1024) ? 10 : 4) : g_dk_attn_mode;
+  // (round 6, profiles/r06_attention_short_sequences.log: at FLUX's 512 x 512 sequence, S = 1280, the one-wave-per-SIMD kernel wins 16 - 26 % on batches -- 240+
+  //  workgroups: a round of the CUs -- and ties on one image in the lab, where the model, with the fused query prologue, measured it 1.6 % per step
+  //  behind the lean kernel: below 2048 tokens it takes the launches that fill at least three quarters of a round; at S = 768 the two tie)
+  const long blocks5 = (long)p.B * p.H * ((p.S + 255) / 256);
+  const bool long5 = p.D == 128 && (p.S >= 2048 || (p.S >= 1024 && blocks5 * 4 >= 3L * dk_device_cu_count()));
+  int mode = p.bias != nullptr ? 4 : g_dk_attn_mode < 0 ? (long5 ? 10 : 4) : g_dk_attn_mode;
   if (mode == 10 && !dk_attention5_eligible(p)) mode = 9;
   dk_prof_begin(2, 4.0 * (double)p.B * p.H * (double)p.S * (double)p.S * p.D, stream);
   int rc = 0;
