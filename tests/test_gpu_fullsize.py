@@ -58,7 +58,7 @@ def check(name, ref, got, f=None, emu_keys=("emu_psnr", "emu_rel_l2")):
     ctx = ""
     if f is not None:
         ctx = ", ".join(f"{k} {float(f[k]):.4g}" for k in emu_keys if k in f.files)
-    print(f"[fullsize] {name}: PSNR {p:.2f} dB, rel-L2 {e:.4e}, max-abs {float((ref.double() - got.double().cpu()).abs().max()):.4g}   (bf16-emulating oracle: {ctx})")
+    print(f"[fullsize] {name}: PSNR {p:.2f} dB, rel-L2 {e:.4e}, max-abs {float((ref.double() - got.double().cpu()).abs().max()):.4g}   (bf16-emulating oracle; emu_fp16_* = the fp16-emulating one, SD3's reference dtype: {ctx})")
     min_p, max_e = TOL[name]
     if min_p is not None:
         assert p >= min_p, f"{name}: PSNR {p:.2f} dB < {min_p}"
@@ -100,6 +100,8 @@ def start_synth_prefetch():
     small = []
     for c, uses in ((fx.SD3_512, 1), (fx.SD3_1024, 1), (fx.FLUX_1024, 2), (fx.FLUX_DEV_512, 2), (fx.SD3_FULL_1024, 3)):
         small.append((_synth_key(c["cfg"], c["seed_w"]), c["cfg"], c["seed_w"], uses))
+    if os.path.exists(os.path.join(GOLD, "fullsize_sd35_full.npz")):  # (8 B parameters, ~40 s: behind the smaller sets)
+        small.append((_synth_key(fx.SD35_FULL["cfg"], fx.SD35_FULL["seed_w"]), fx.SD35_FULL["cfg"], fx.SD35_FULL["seed_w"], 1))
     big = [(_synth_key(fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"]), fx.FLUX_FULL["cfg"], fx.FLUX_FULL["seed_w"], 1)]
     _SYNTH_PLAN.extend(big + small)
     for plan in (big, small):
@@ -181,7 +183,7 @@ def test_sd3_medium_512_full_depth_pipeline(dev):
     lat, iter_time = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
                                           seed=c["noise_seed"])
     assert len(iter_time) == c["steps"] and lat.shape == (1, 64, 64, 16)
-    check("sd3_512_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
+    check("sd3_512_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs", "emu_fp16_psnr", "emu_fp16_rel_l2"))
     # decode the ORACLE's latent (the image fixture was decoded from it), so that the image check isolates the VAE at 512 x 512
     img, u8, _ = pipe.decoder.decode(torch.from_numpy(f["latent_fp32"]).to(dev))
     check("sd3_512_image", torch.from_numpy(f["image_fp32_f16"].astype(np.float32)), img.cpu())
@@ -341,6 +343,7 @@ FORCED_TOL = {
     "flux_dev_full_fp8": (29.6, 1.5e-1),  # measured 31.62-32.53 dB / 8.6e-2-1.02e-1 (e4m3 weights + MX-fp8 activations against the un-quantised oracle)
     # round 5: the fp8 precision policy (first 12 double blocks bf16): the bar of SURVEY.md section 8c (iii), not measured - 2 dB -- measured 35.14-36.36 dB / 6.5e-2
     "flux_dev_full_fp8_policy": (35.0, 7.5e-2),
+    "sd35_full": (40.0, 5.0e-2),       # round 6: placeholder until measured (SD3.5-large, 38 blocks; set to measured - 2 dB / x 1.5 in profiles/r06_fullsize_parity.log)
     "sd3_full_late": (46.0, 2.5e-2),   # measured 47.98-49.55 dB / 1.58e-2-1.69e-2 (CFG 5 amplifies; bf16-emulating oracle 47.6-49.2 dB / 1.64e-2-1.75e-2)
 }
 
@@ -351,6 +354,8 @@ def check_forced(name, f, got, tol_key):
         ref = torch.from_numpy(f[f"d{i}_fp32_f16"].astype(np.float32))
         p, e = psnr(ref, got[i].float()), rel_l2(ref, got[i].float())
         emu = f", bf16-emulating oracle {float(f[f'd{i}_emu_psnr']):.2f} dB / {float(f[f'd{i}_emu_rel_l2']):.3e}" if f"d{i}_emu_psnr" in f.files else ""
+        if f"d{i}_emu_fp16_psnr" in f.files:  # (round 6: the reference's own dtype for SD3, mlx/config.py:79 -- context, not a gate)
+            emu += f", fp16-emulating oracle {float(f[f'd{i}_emu_fp16_psnr']):.2f} dB / {float(f[f'd{i}_emu_fp16_rel_l2']):.3e}"
         print(f"[fullsize] {name} step {i + 1} of 50: Euler direction PSNR {p:.2f} dB, rel-L2 {e:.4e} (|d| rms {float(f[f'd{i}_rms']):.3f}{emu})")
         worst_p, worst_e = min(worst_p, p), max(worst_e, e)
     min_p, max_e = FORCED_TOL[tol_key]
@@ -388,6 +393,21 @@ def test_sd3_medium_1024_full_depth_cfg_late_steps(dev):
     packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True)}
     pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed)
     check_forced("sd3_full_late", f, forced_steps(pipe, c, dev), "sd3_full_late")
+
+
+def test_sd35_large_1024_full_depth_cfg_forced_steps(dev):
+    """Round 6 (VERDICT r5 missing 9): the reference's third model family (mlx/config.py:72-74) at FULL depth -- SD3.5-large, 38 blocks of width 2432
+    (N % 256 = 128: the half column tile of gemm256v3.hip on every Linear), 38 heads of 64, QK-norm, B = 2 (CFG 5.0), 589 text tokens, latent 128 x 128:
+    the first and the last step of the 50-step schedule, teacher-forced, Euler direction against the fp32 oracle"""
+    from diffusionkit_amd.pipeline import DiffusionPipeline
+    f = load("sd35_full")
+    c = fx.SD35_FULL
+    packed = {"mmdit": pack_mmdit(c["cfg"], synth_cached(c["cfg"], c["seed_w"]), dev, consume=True)}
+    pipe = DiffusionPipeline(w16=True, a16=True, shift=c["shift"], device=dev, text_len=c["S_t"], packed_weights=packed, mmdit_config=c["cfg"],
+                             model_version="argmaxinc/mlx-stable-diffusion-3.5-large")
+    check_forced("sd35_full", f, forced_steps(pipe, c, dev), "sd35_full")
+    del pipe, packed
+    torch.cuda.empty_cache()
 
 
 # ---- round 5: closed-loop trajectories of the 50-step configurations (VERDICT r4 "Next round" item 2) ---------------------------------
