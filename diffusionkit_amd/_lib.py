@@ -98,10 +98,15 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 _fp = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); must list every symbol include/dk_hip.h declares
+class dk_gemm_plan_t(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kernel", "tile_rows", "tiles", "workgroups", "split_tiles", "k_pieces", "ks", "n_cu", "launches")]
+
+
 SIGNATURES = {
     "dk_abi_version": (_i32, []),
     "dk_last_error": (C.c_char_p, []),
     "dk_gemm_bf16": (_i32, [C.POINTER(dk_gemm_desc), _vp]),
+    "dk_gemm_plan": (_i32, [C.POINTER(dk_gemm_desc), C.POINTER(dk_gemm_desc), C.POINTER(dk_gemm_plan_t)]),
     "dk_gemm_workspace_bytes": (C.c_size_t, []),
     "dk_attention_workspace_bytes": (C.c_size_t, []),
     "dk_attention_set_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -180,7 +185,7 @@ def load() -> C.CDLL:
             raise DkHipError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dk_abi_version() != 4:
+    if lib.dk_abi_version() != 5:
         raise DkHipError("libdk_hip.so ABI version mismatch")
     _lib = lib
     return lib

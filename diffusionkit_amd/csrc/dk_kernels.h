@@ -56,6 +56,20 @@ struct GemmParams {
   int qn_col0, qn_col1;
 };
 int dk_launch_gemm(const GemmParams& p, hipStream_t stream);
+// Plan mode (dk_gemm_plan / dk_gemm_pair_plan, host only): while g_dk_gemm_plan points at a record, the launchers fill it with what they WOULD launch and
+// return without touching the device -- the decision code is the launch code itself, so a CPU test can sweep shapes over the dispatch rules
+struct DkGemmPlan {
+  int kernel;      // 128: dk_gemm_bf16_kernel (128 x 128 tiles), 3: dk_gemm256v3_kernel (8 waves), 4: dk_gemm256v4_kernel (one wave per SIMD)
+  int tile_rows;   // 128 / 224 / 256
+  int tiles;       // output tiles of the launch (both problems of a grouped one)
+  int workgroups;  // grid size (tiles that are cut along K count once per piece)
+  int split_tiles; // tiles cut along K (0: none)
+  int k_pieces;    // pieces per cut tile
+  int ks;          // K-tile steps (64 elements each) of the finisher piece; whole tiles: K / 64
+  int n_cu;        // compute units the rules assumed
+  int launches;    // kernel launches the call expands to (a column split or a fused-norm fallback on the small kernel: 2)
+};
+extern thread_local DkGemmPlan* g_dk_gemm_plan;
 extern int g_dk_gemm_mode;
 extern int g_dk_v3_split;  // gemm256v3.hip: remainder-wave K split (-1 auto, 0 off, 1 whenever possible)
 extern int g_dk_v3_split_min;  // ... saved K-tile steps below which an all-remainder Linear stays whole (-1: default)

@@ -83,6 +83,20 @@ extern "C" int dk_gemm_bf16(const dk_gemm_desc* d, void* stream) {
   return dk_launch_gemm(gemm_params_from_desc(d), S_(stream));
 }
 
+extern "C" int dk_gemm_plan(const dk_gemm_desc* d, const dk_gemm_desc* d2, dk_gemm_plan_t* plan) {
+  DK_REQUIRE(d != nullptr && plan != nullptr, "null descriptor / plan");
+  static_assert(sizeof(dk_gemm_plan_t) == sizeof(DkGemmPlan), "the ABI record mirrors the launchers' record");
+  DkGemmPlan rec;
+  memset(&rec, 0, sizeof(rec));
+  struct Scope {  // (the launchers see the record only for the duration of this call, whatever path returns)
+    explicit Scope(DkGemmPlan* r) { g_dk_gemm_plan = r; }
+    ~Scope() { g_dk_gemm_plan = nullptr; }
+  } scope(&rec);
+  const int rc = d2 != nullptr ? dk_launch_gemm_pair(gemm_params_from_desc(d), gemm_params_from_desc(d2), nullptr) : dk_launch_gemm(gemm_params_from_desc(d), nullptr);
+  memcpy(plan, &rec, sizeof(rec));
+  return rc;
+}
+
 // workspace: optional K-split scratch (dk_gemm_split_workspace_bytes) for stages whose tiles fill only half the CUs
 static int conv3x3_launch(const dk_conv_desc* d, void* workspace, hipStream_t stream) {
   DK_REQUIRE(d != nullptr, "null descriptor");

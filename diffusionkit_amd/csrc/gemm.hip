@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void dk_gemm_bf16_kernel(GemmParams p) {
 // tuning knob (dk_tune_set("gemm", v)): -1 = automatic choice, 128 = always the 128^2-tile kernel of this file, 9 = the 256^2 kernel
 // (gemm256v3.hip) on every shape it accepts, 10 = the one-wave-per-SIMD 256^2 kernel (gemm256v4.hip) on every shape IT accepts (others: 9)
 int g_dk_gemm_mode = -1;
+thread_local DkGemmPlan* g_dk_gemm_plan = nullptr;
 
 // Which of the two 256^2 kernels takes a launch both accept.  gemm256v4.hip (one wave per SIMD, asm body) runs its K loop 5-7 % faster
 // (profiles/r05_gemm_v4_*.log: 8192^3 1587 against 1488 TF with cold weights, the model's linear1 / linear2 / fc1 / fc2 +4-5 %), but has no
@@ -322,6 +323,12 @@ int dk_launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   if (p.epi == DK_EPI_GATE_RES) DK_REQUIRE(p.gate && p.res, "gate/res missing");
   if (p.epi == DK_EPI_RES) DK_REQUIRE(p.res, "res missing");
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  if (g_dk_gemm_plan != nullptr) {
+    DkGemmPlan& pl = *g_dk_gemm_plan;
+    pl.kernel = 128; pl.tile_rows = BM; pl.tiles = pl.workgroups = nbm * nbn; pl.split_tiles = 0; pl.k_pieces = 1; pl.ks = p.K / BK;
+    pl.n_cu = dk_device_cu_count(); pl.launches += 1;
+    return 0;
+  }
   static DkDeviceOnce attr_once;
   if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));

@@ -949,14 +949,6 @@ bool dk_gemm256v3_splits_whole_launch(const GemmParams& p, const GemmParams* p2)
 
 // `p2` null: one problem.  (tiles_a / tiles_b of older callers are recomputed here: they depend on the tile height)
 int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*tiles_a*/, int tiles_b_in, hipStream_t stream) {
-  static DkDeviceOnce attr_once;
-  if (attr_once.first()) {
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_once.mark();
-  }
   const int n_cu = dk_device_cu_count();
   const bool two = tiles_b_in > 0;
   const bool have_ws = v3_have_ws(p, two ? &pb : nullptr);
@@ -965,6 +957,20 @@ int dk_launch_gemm256v3_raw(const GemmParams& p, const GemmParams& pb, int /*til
   const int tiles_a = ((p.M + bm - 1) / bm) * ((p.N + T256 - 1) / T256);
   const int tiles_b = two ? ((pb.M + bm - 1) / bm) * ((pb.N + T256 - 1) / T256) : 0;
   const SplitPlan pl = plan_split(tiles_a + tiles_b, p.K / BK, have_ws, n_cu, !p.conv);
+  if (g_dk_gemm_plan != nullptr) {
+    DkGemmPlan& gp = *g_dk_gemm_plan;
+    gp.kernel = 3; gp.tile_rows = bm; gp.tiles = tiles_a + tiles_b; gp.workgroups = pl.n_dp + pl.n_rem * pl.S; gp.split_tiles = pl.n_rem;
+    gp.k_pieces = pl.n_rem > 0 ? pl.S : 1; gp.ks = pl.n_rem > 0 ? pl.ks : p.K / BK; gp.n_cu = n_cu; gp.launches += 1;
+    return 0;
+  }
+  static DkDeviceOnce attr_once;
+  if (attr_once.first()) {
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v3_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_once.mark();
+  }
   SplitArgs sp;
   memset(&sp, 0, sizeof(sp));
   sp.n_dp = pl.n_dp; sp.n_rem = pl.n_rem; sp.S = pl.S; sp.ks = pl.ks;
@@ -998,6 +1004,7 @@ int dk_launch_gemm256v3(const GemmParams& p, const GemmParams* p2, hipStream_t s
   }
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
+  if (g_dk_gemm_plan != nullptr) return dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, 0, p2 ? 1 : 0, stream);  // (plan mode: no device call)
   dk_prof_begin(p.conv ? 1 : 0, work, stream);
   const int rc = dk_launch_gemm256v3_raw(p, p2 ? *p2 : p, 0, p2 ? 1 : 0, stream);
   dk_prof_end(stream);

@@ -474,17 +474,23 @@ int dk_launch_gemm256v4(const GemmParams& p, const GemmParams* p2, hipStream_t s
                    (p.n_split == 0 || p2->epi2 == p.epi2),
                "grouped GEMM: N, K, epilogue must match");
   }
+  const int n_cu = dk_device_cu_count();
+  const int mf = dk_gemm256v4_pick_mf(p, p2, n_cu);
+  const int bm = 32 * mf;
+  const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / 256);
+  const int tiles_b = p2 ? ((p2->M + bm - 1) / bm) * (p2->N / 256) : 0;
+  if (g_dk_gemm_plan != nullptr) {
+    DkGemmPlan& pl = *g_dk_gemm_plan;
+    pl.kernel = 4; pl.tile_rows = bm; pl.tiles = pl.workgroups = tiles_a + tiles_b; pl.split_tiles = 0; pl.k_pieces = 1; pl.ks = p.K / V4_BK;
+    pl.n_cu = n_cu; pl.launches += 1;
+    return 0;
+  }
   static DkDeviceOnce attr_once;
   if (attr_once.first()) {
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
     DK_CHECK_HIP(hipFuncSetAttribute((const void*)dk_gemm256v4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES));
     attr_once.mark();
   }
-  const int n_cu = dk_device_cu_count();
-  const int mf = dk_gemm256v4_pick_mf(p, p2, n_cu);
-  const int bm = 32 * mf;
-  const int tiles_a = ((p.M + bm - 1) / bm) * (p.N / 256);
-  const int tiles_b = p2 ? ((p2->M + bm - 1) / bm) * (p2->N / 256) : 0;
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(0, work, stream);

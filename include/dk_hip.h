@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 4
+#define DK_ABI_VERSION 5
 
 int dk_abi_version(void);
 const char* dk_last_error(void);
@@ -78,6 +78,23 @@ size_t dk_gemm_workspace_bytes(void);
 /* nn.Linear call sites of the hot path: mmdit.py:56,358-360,373-375,432,771,777,821-832;
  * vae.py:36-39,84 */
 int dk_gemm_bf16(const dk_gemm_desc* d, void* stream);
+
+/* What dk_gemm_bf16(d) -- or, with d2 != NULL, the grouped launch the engines issue for the image and text streams of a double block -- WOULD
+ * launch on the current device (ABI 5, round 6).  Host only: no kernel runs, pointers in the descriptors are not dereferenced (only their alignment
+ * is looked at; `workspace` non-NULL tells the rules that the K split is available), and without a GPU the rules assume 256 compute units.  The
+ * decision code is the launch code itself, so tests/test_dispatch_plan.py sweeps shapes over the dispatch rules on the CPU. */
+typedef struct dk_gemm_plan_t {
+  int32_t kernel;      /* 128: 128 x 128-tile kernel; 3: 256 x 256 tiles, 8 waves (gemm256v3.hip); 4: one wave per SIMD (gemm256v4.hip) */
+  int32_t tile_rows;   /* 128 / 224 / 256 */
+  int32_t tiles;       /* output tiles of the launch */
+  int32_t workgroups;  /* grid size: a tile that is cut along K counts once per piece */
+  int32_t split_tiles; /* tiles cut along K */
+  int32_t k_pieces;    /* pieces per cut tile (1: none) */
+  int32_t ks;          /* K steps of 64 elements a workgroup runs (the finisher piece of a cut tile) */
+  int32_t n_cu;        /* compute units the rules assumed */
+  int32_t launches;    /* kernel launches the call expands to */
+} dk_gemm_plan_t;
+int dk_gemm_plan(const dk_gemm_desc* d, const dk_gemm_desc* d2, dk_gemm_plan_t* plan);
 
 typedef struct dk_conv_desc {
   const void* x;    /* NHWC bf16 [B, H(/2), W(/2), C]; C multiple of 64              */

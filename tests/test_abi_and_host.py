@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dk_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.dk_abi_version() == 4
+    assert lib.dk_abi_version() == 5
 
 
 def test_mod_table_layout_matches_config():
