@@ -72,6 +72,7 @@ struct DkGemmPlan {
 extern thread_local DkGemmPlan* g_dk_gemm_plan;
 extern int g_dk_gemm_mode;
 extern int g_dk_v3_split;  // gemm256v3.hip: remainder-wave K split (-1 auto, 0 off, 1 whenever possible)
+extern int g_dk_pair_split_nk;  // gemm.hip: see dk_launch_gemm_pair
 extern int g_dk_v3_split_min;  // ... saved K-tile steps below which an all-remainder Linear stays whole (-1: default)
 extern int g_dk_v3_mf;     // gemm256v3.hip: wave-tile height in 16-row fragments (-1 auto, 8 = 256-row tiles, 7 = 224-row tiles)
 // workspace of the remainder-wave K split (fp32 slabs + flags; its last 4 KiB -- the flag region -- must be zero before the first

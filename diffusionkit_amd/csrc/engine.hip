@@ -46,6 +46,7 @@ extern "C" int dk_tune_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm_fuse_q") == 0) { g_dk_fuse_qg = value; return 0; }
   if (strcmp(key, "gemm_split") == 0) { g_dk_v3_split = value; return 0; }
   if (strcmp(key, "gemm_split_min") == 0) { g_dk_v3_split_min = value; return 0; }
+  if (strcmp(key, "gemm_pair_nk") == 0) { g_dk_pair_split_nk = value; return 0; }
   if (strcmp(key, "gemm_mf") == 0) { g_dk_v3_mf = value; return 0; }
   if (strcmp(key, "pitch_min_k") == 0) { g_dk_pitch_min_k = value; return 0; }
   if (strcmp(key, "conv_halo") == 0) { g_dk_conv_halo = value; return 0; }
