@@ -410,10 +410,13 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
  * "gemm": 128 = 128x128 tiles only, 9 = the 8-wave 256x256 kernel on every shape it accepts, 10 = the one-wave-per-SIMD 256x256 kernel
  * (asm body) on every shape IT accepts; "gemm_v4": 0 = the automatic choice never takes the latter; "gemm_skew": start skew of that kernel's
  * multi-round launches in 0.25 us steps (-1: none); "gemm_mf": 8 / 7 = 256- / 224-row
- * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
+ * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_split_min": K-tile steps a workgroup must save before a
+ * Linear of at most half a round of tiles is cut along K as a whole (default 48); "gemm_pair_nk": K-tile steps from which an image + text pair with
+ * a small extra round is grouped and cut (default 32); "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
  * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise; 10 one-wave-per-SIMD kernel with the generated asm
- * tile loop: head_dim 128, S a multiple of 256 and >= 768, falls back to 9 otherwise -- the automatic choice from S = 2048 on);
+ * tile loop: head_dim 128, S a multiple of 256 and >= 768, falls back to 9 otherwise -- the automatic choice from S = 2048 on, and from
+ * S = 1024 for launches of at least three quarters of a round of 256-query blocks);
  * "attn_split": key ranges of the one-wave-per-SIMD kernel's last-round query blocks (-1 automatic, 0 never, 2..4);
  * "attn_fuse_q": 0 = stand-alone query QKNorm + RoPE pass; "conv_halo": 0 = VAE convolutions through the GEMM form;
  * "conv_v4": the fused VAE convolutions with >= 256 output channels on the one-wave-per-SIMD kernel (1 where one image fills the
