@@ -40,6 +40,8 @@ Round 5 (VERDICT r4 "Next round" item 2: CLOSED-LOOP runs of the 50-step configu
   flux_dev_10    BASELINE configs[3]'s shape closed loop: 19 + 38 blocks at FLUX width, S_t = 512, a complete 10-step schedule
                  (sigma 1 -> 0) -> the latent after steps 1, 2, 5 (fp16) and 10 (fp32); replayed with bf16 and with fp8 weights
 
+Round 6: flux_512 -- FLUX.1-schnell, all 57 blocks, 4 Euler steps at 512 x 512 (latent 64 x 64, S = 1280: the reference CLI's default resolution) -> final
+                 latent, fp32 oracle + the bf16-emulating one
 Round 6 (VERDICT r5 missing 9): sd35_full -- SD3.5-large (38 blocks, width 2432, QK-norm) at full depth, B = 2, CFG 5.0, steps 1 and 50 of the
                  50-step schedule teacher-forced (the Euler direction of each, fp32 oracle + what the bf16-emulating oracle reaches)
 Round 6 (VERDICT r5 "Next round" item 4: configs[3] closed loop at its STATED length):
@@ -135,6 +137,11 @@ FLUX_DEV_10 = dict(cfg=FLUX_SCHNELL, seed_w=1234, latent=(128, 128), S_t=512, st
 # last Euler step of the 50-step schedule, teacher-forced like sd3_full_late
 SD35_FULL = dict(cfg=SD3_8b, seed_w=1234, latent=(128, 128), S_t=589, steps_of=50, shift=3.0, cfg_weight=5.0, flux=False,
                  step_ids=(0, 49), noise_seed=0, clean_seed=93, text_seed=83, rows=2)
+
+
+# ---- round 6 case: FLUX.1-schnell end to end at the resolution the reference's CLI defaults to (generate_images.py:15-30): latent 64 x 64, S = 1280 --
+# the launches the round's small-launch rules changed (fc2 / linear2 cut along K inside the model)
+FLUX_512 = dict(FLUX_FULL, latent=(64, 64))
 
 
 # ---- round 6 case: configs[3]'s shape closed loop at its STATED length ---------------------------------------------
@@ -550,7 +557,8 @@ CASES = {"sd3_fp16_context": make_sd3_fp16_context, "flux_dev_50": lambda: make_
          "flux_blocks": make_flux_blocks,
          "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", True),
          "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True),
-         "sd35_full": lambda: make_forced(SD35_FULL, "sd35_full", True)}
+         "sd35_full": lambda: make_forced(SD35_FULL, "sd35_full", True),
+         "flux_512": lambda: make_flux_full(True, FLUX_512, "flux_512")}
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("DK_FIXTURE_THREADS", os.cpu_count() or 8)))

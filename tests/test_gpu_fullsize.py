@@ -43,6 +43,8 @@ TOL = {
     "sd3_full_1024_x3": (71.2, 1.6e-3),         # configs[2] at full depth: 24 blocks, B 2, CFG 5, first 3 of 50 Euler steps
     "flux_full_latent": (52.4, 1.28e-2),      # BASELINE configs[1] end to end (57 blocks x 4 steps), round-3 fixture (the reference's bf16 timestep embedding in the oracle)
     "flux_full_fp8_latent": (35.3, 9.0e-2),  # the same image with e4m3 weights / MX-fp8 activations on every block Linear
+    # ---- round 6 ----
+    "flux_512_latent": (48.0, 2.0e-2),       # placeholder until measured (FLUX.1-schnell at the reference CLI's 512 x 512 default: the K-split launches inside the model)
 }
 
 
@@ -247,6 +249,20 @@ def test_flux_schnell_1024_full_depth_pipeline(dev):
     lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
                                   seed=c["noise_seed"])
     check("flux_full_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
+
+
+def test_flux_schnell_512_full_depth_pipeline(dev):
+    """Round 6: FLUX.1-schnell end to end at the resolution the reference's CLI defaults to (mlx/scripts/generate_images.py:15-30: 512 x 512 = latent
+    64 x 64, S = 1280), 19 + 38 blocks, 4 Euler steps -- the configuration whose fc2 / linear2 launches (60 tiles) the round's small-launch rule cuts along K
+    and hands to the 8-wave kernel -- against the fp32 oracle's latent"""
+    f = load("flux_512")
+    c = fx.FLUX_512
+    pipe = flux_full_pipe(dev)
+    text, pooled = fx.flux_full_inputs()
+    lat, _ = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"],
+                                  seed=c["noise_seed"])
+    assert lat.shape == (1, 64, 64, 16)
+    check("flux_512_latent", torch.from_numpy(f["latent_fp32"]), lat.cpu(), f, ("emu_psnr", "emu_rel_l2", "emu_max_abs"))
 
 
 def test_flux_schnell_1024_full_depth_pipeline_fp8_weights(dev):
