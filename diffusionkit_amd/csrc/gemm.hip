@@ -357,16 +357,16 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
     // group only when the extra tiles do not open another wave of the 256 CUs (kernel lab: a partial extra wave costs more
     // than the small separate launch) ...
     const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
+    const long n_cu = dk_device_cu_count();  // (rounds in units of THIS device's CUs; the fractions below were fitted on 256)
     // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
-    const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % 256 <= 64 && a.K / 64 >= (g_dk_pair_split_nk >= 0 ? g_dk_pair_split_nk : 32);
+    const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % n_cu <= n_cu / 4 && a.K / 64 >= (g_dk_pair_split_nk >= 0 ? g_dk_pair_split_nk : 32);
     // (gemm256v4.hip: the same test at ITS tile height -- with 224-row tiles the image + text fc1 of FLUX is 912 + 96 tiles: both 4 rounds)
     if (dk_gemm256v4_eligible(a) && dk_gemm256v4_eligible(b)) {
-      const long n_cu = dk_device_cu_count();
       const int bm4 = 32 * dk_gemm256v4_pick_mf(a, &b, (int)n_cu);
       const long ta4 = (long)((a.M + bm4 - 1) / bm4) * (a.N / 256), tb4 = (long)((b.M + bm4 - 1) / bm4) * (b.N / 256);
       if ((ta4 + n_cu - 1) / n_cu == (ta4 + tb4 + n_cu - 1) / n_cu && dk_use_v4(a, &b)) return dk_launch_gemm256v4(a, &b, stream);
     }
-    if ((ta + 255) / 256 == (ta + tb + 255) / 256 || split_ok) return dk_launch_gemm256v3(a, &b, stream);
+    if ((ta + n_cu - 1) / n_cu == (ta + tb + n_cu - 1) / n_cu || split_ok) return dk_launch_gemm256v3(a, &b, stream);
   }
   int rc = dk_launch_gemm(a, stream);
   if (rc) return rc;
