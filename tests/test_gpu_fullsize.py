@@ -60,7 +60,7 @@ def check(name, ref, got, f=None, emu_keys=("emu_psnr", "emu_rel_l2")):
     ctx = ""
     if f is not None:
         ctx = ", ".join(f"{k} {float(f[k]):.4g}" for k in emu_keys if k in f.files)
-    print(f"[fullsize] {name}: PSNR {p:.2f} dB, rel-L2 {e:.4e}, max-abs {float((ref.double() - got.double().cpu()).abs().max()):.4g}   (bf16-emulating oracle; emu_fp16_* = the fp16-emulating one, SD3's reference dtype: {ctx})")
+    print(f"[fullsize] {name}: PSNR {p:.2f} dB, rel-L2 {e:.4e}, max-abs {float((ref.double() - got.double().cpu()).abs().max()):.4g}   (bf16-emulating oracle{'; emu_fp16_*: the fp16-emulating one, SD3 reference dtype' if 'fp16' in ctx else ''}: {ctx})")
     min_p, max_e = TOL[name]
     if min_p is not None:
         assert p >= min_p, f"{name}: PSNR {p:.2f} dB < {min_p}"
