@@ -43,7 +43,7 @@ Round 5 (VERDICT r4 "Next round" item 2: CLOSED-LOOP runs of the 50-step configu
 Round 6: flux_512 -- FLUX.1-schnell, all 57 blocks, 4 Euler steps at 512 x 512 (latent 64 x 64, S = 1280: the reference CLI's default resolution) -> final
                  latent, fp32 oracle + the bf16-emulating one
 Round 6 (VERDICT r5 missing 9): sd35_full -- SD3.5-large (38 blocks, width 2432, QK-norm) at full depth, B = 2, CFG 5.0, steps 1 and 50 of the
-                 50-step schedule teacher-forced (the Euler direction of each, fp32 oracle + what the bf16-emulating oracle reaches)
+                 50-step schedule teacher-forced (the Euler direction of each, fp32 oracle)
 Round 6 (VERDICT r5 "Next round" item 4: configs[3] closed loop at its STATED length):
   flux_dev_50    the same model, conditioning and start noise over the complete 50-step schedule (fp32 oracle, ~3 h on 5 cores) -> the
                  latent after steps 1, 2, 5, 10, 20, 30, 40 (fp16) and 50 (fp32); replayed with bf16, the fp8 policy and every block fp8
@@ -557,7 +557,7 @@ CASES = {"sd3_fp16_context": make_sd3_fp16_context, "flux_dev_50": lambda: make_
          "flux_blocks": make_flux_blocks,
          "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", True),
          "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True),
-         "sd35_full": lambda: make_forced(SD35_FULL, "sd35_full", True),
+         "sd35_full": lambda: make_forced(SD35_FULL, "sd35_full", False),  # (fp32 oracle only: the bf16-emulating pass on 8 B parameters ran this 62 GB host out of memory)
          "flux_512": lambda: make_flux_full(True, FLUX_512, "flux_512")}
 
 if __name__ == "__main__":
