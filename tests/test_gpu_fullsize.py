@@ -435,6 +435,10 @@ CLOSED_TOL = {
     "flux_dev_10": (54.4, 1.01e-2),             # measured 56.49 dB / 6.73e-3 (bf16 weights, 10 closed-loop steps, sigma 1 -> 0)
     "flux_dev_10_fp8": (36.8, 7.7e-2),           # measured 38.83 dB / 5.14e-2 (every block Linear in fp8: ten ~32 dB steps)
     "flux_dev_10_fp8_policy": (40.9, 4.8e-2),    # measured 42.93 dB / 3.21e-2 (the shipped precision policy: first 12 double blocks bf16)
+    # round 6: the same at configs[3]'s STATED length, 50 steps (placeholders until measured; then measured - 2 dB / x 1.5, profiles/r06_fullsize_parity.log)
+    "flux_dev_50": (45.0, 3.0e-2),
+    "flux_dev_50_fp8": (28.0, 2.0e-1),
+    "flux_dev_50_fp8_policy": (32.0, 1.2e-1),
 }
 
 
@@ -480,14 +484,14 @@ def test_sd3_medium_1024_closed_loop_50_steps(dev):
     assert p_img >= CLOSED_TOL["sd3_full_50_image"][0]
 
 
-def _flux_dev_10(dev, fp8, key):
-    f = load("flux_dev_10")
-    c = fx.FLUX_DEV_10
+def _flux_dev_10(dev, fp8, key, case="flux_dev_10"):
+    f = load(case)
+    c = fx.FLUX_DEV_10 if case == "flux_dev_10" else fx.FLUX_DEV_50
     pipe = flux_full_pipe(dev, fp8=fp8)
     text, pooled = fx.flux_dev_10_inputs()
     lat, it = pipe.denoise_latents(text.to(dev, BF), pooled.to(dev, BF), num_steps=c["steps"], cfg_weight=0.0, latent_size=c["latent"], seed=c["noise_seed"])
     assert len(it) == c["steps"]
-    check_closed(f"flux_dev_10 ({key})", torch.from_numpy(f["latent_fp32"]), lat.float().cpu(), key)
+    check_closed(f"{case} ({key})", torch.from_numpy(f["latent_fp32"]), lat.float().cpu(), key)
 
 
 def test_flux_dev_shape_closed_loop_10_steps(dev):
@@ -504,6 +508,24 @@ def test_flux_dev_shape_closed_loop_10_steps_fp8(dev):
 def test_flux_dev_shape_closed_loop_10_steps_fp8_policy(dev):
     """... and the shipped precision policy (first 12 double-stream blocks bf16)"""
     _flux_dev_10(dev, "quality", "flux_dev_10_fp8_policy")
+
+
+def test_flux_dev_shape_closed_loop_50_steps(dev):
+    """Round 6: BASELINE configs[3] at its STATED length, closed loop -- 19 + 38 blocks, S_t = 512, all 50 Euler steps of the 50-step
+    schedule through denoise_latents, every step from the latent the previous one left; bf16 weights, final latent against the fp32 oracle's
+    (tests/golden/fullsize_flux_dev_50.npz: 2.8 h of the CPU oracle)"""
+    _flux_dev_10(dev, False, "flux_dev_50", "flux_dev_50")
+
+
+def test_flux_dev_shape_closed_loop_50_steps_fp8_policy(dev):
+    """... configs[3] as shipped: e4m3 weights / MX-fp8 activations with the precision policy (first 12 double-stream blocks bf16): what fifty ~35 dB
+    steps accumulate to"""
+    _flux_dev_10(dev, "quality", "flux_dev_50_fp8_policy", "flux_dev_50")
+
+
+def test_flux_dev_shape_closed_loop_50_steps_fp8(dev):
+    """... and every block Linear in fp8 (fifty ~32 dB steps)"""
+    _flux_dev_10(dev, True, "flux_dev_50_fp8", "flux_dev_50")
 
 
 def test_eight_seeds_one_step_loop_equal_single_runs(dev):
