@@ -435,10 +435,11 @@ CLOSED_TOL = {
     "flux_dev_10": (54.4, 1.01e-2),             # measured 56.49 dB / 6.73e-3 (bf16 weights, 10 closed-loop steps, sigma 1 -> 0)
     "flux_dev_10_fp8": (36.8, 7.7e-2),           # measured 38.83 dB / 5.14e-2 (every block Linear in fp8: ten ~32 dB steps)
     "flux_dev_10_fp8_policy": (40.9, 4.8e-2),    # measured 42.93 dB / 3.21e-2 (the shipped precision policy: first 12 double blocks bf16)
-    # round 6: the same at configs[3]'s STATED length, 50 steps (placeholders until measured; then measured - 2 dB / x 1.5, profiles/r06_fullsize_parity.log)
-    "flux_dev_50": (45.0, 3.0e-2),
-    "flux_dev_50_fp8": (28.0, 2.0e-1),
-    "flux_dev_50_fp8_policy": (32.0, 1.2e-1),
+    # round 6: the same at configs[3]'s STATED length, all 50 steps closed loop (profiles/r06_fullsize_parity.log); gates = measured - 2 dB / x 1.5.  Fifty small
+    # steps end CLOSER to the oracle than ten large ones: the latent integrates the directions with weights dt that sum to one, each taken nearer its neighbour
+    "flux_dev_50": (56.1, 8.2e-3),              # measured 58.11 dB / 5.46e-3 (bf16 weights)
+    "flux_dev_50_fp8": (37.4, 7.1e-2),           # measured 39.44 dB / 4.68e-2 (every block Linear in fp8: fifty ~32 dB steps)
+    "flux_dev_50_fp8_policy": (41.4, 4.5e-2),    # measured 43.44 dB / 2.95e-2 (configs[3] as shipped: first 12 double blocks bf16, every step >= 35 dB)
 }
 
 
