@@ -44,7 +44,7 @@ TOL = {
     "flux_full_latent": (52.4, 1.28e-2),      # BASELINE configs[1] end to end (57 blocks x 4 steps), round-3 fixture (the reference's bf16 timestep embedding in the oracle)
     "flux_full_fp8_latent": (35.3, 9.0e-2),  # the same image with e4m3 weights / MX-fp8 activations on every block Linear
     # ---- round 6 ----
-    "flux_512_latent": (48.0, 2.0e-2),       # placeholder until measured (FLUX.1-schnell at the reference CLI's 512 x 512 default: the K-split launches inside the model)
+    "flux_512_latent": (52.0, 1.32e-2),      # FLUX.1-schnell end to end at the reference CLI's 512 x 512 default (the K-split launches inside the model): measured 54.06 dB / 8.79e-3 (emu 54.09 dB)
 }
 
 
@@ -359,7 +359,7 @@ FORCED_TOL = {
     "flux_dev_full_fp8": (29.6, 1.5e-1),  # measured 31.62-32.53 dB / 8.6e-2-1.02e-1 (e4m3 weights + MX-fp8 activations against the un-quantised oracle)
     # round 5: the fp8 precision policy (first 12 double blocks bf16): the bar of SURVEY.md section 8c (iii), not measured - 2 dB -- measured 35.14-36.36 dB / 6.5e-2
     "flux_dev_full_fp8_policy": (35.0, 7.5e-2),
-    "sd35_full": (40.0, 5.0e-2),       # round 6: placeholder until measured (SD3.5-large, 38 blocks; set to measured - 2 dB / x 1.5 in profiles/r06_fullsize_parity.log)
+    "sd35_full": (44.5, 2.4e-2),       # round 6: SD3.5-large at full depth (38 blocks, width 2432, CFG 5): measured 46.52-47.66 dB / 1.60e-2
     "sd3_full_late": (46.0, 2.5e-2),   # measured 47.98-49.55 dB / 1.58e-2-1.69e-2 (CFG 5 amplifies; bf16-emulating oracle 47.6-49.2 dB / 1.64e-2-1.75e-2)
 }
 
