@@ -20,6 +20,9 @@ for tag, M in (("512^2", 1280), ("768^2", 2560), ("1024^2", 4352)):
     shapes += [(f"{tag} o", M, h, h), (f"{tag} fc2", M, h, 4 * h), (f"{tag} linear2", M, h, 5 * h), (f"{tag} qkv", M, 3 * h, h), (f"{tag} fc1", M, 4 * h, h),
                (f"{tag} linear1", M, 7 * h, h)]
 modes = [("auto", {}), ("v4 forced", {"gemm_v4": 2}), ("v3 no split", {"gemm": 9, "gemm_split": 0}), ("v3 split", {"gemm": 9})]
+if os.environ.get("SMALLK"):  # the 128 x 128-tile kernel on the launches that are a fraction of a round of 256 x 256 tiles (240 workgroups at M = 1280, N = 3072)
+    modes = [("auto", {}), ("128^2 kernel", {"gemm": 128})]
+    shapes = [s for s in shapes if not s[0].startswith("1024")]
 if os.environ.get("FORCED"):  # the producer-chain split of a remainder of MORE than half the CUs (finisher [0, ks) + c producer pieces in turn on each spare CU): stream-K's 4/5 form
     modes = [("v4", {"gemm_v4": 2}), ("v3 no split", {"gemm": 9, "gemm_split": 0}), ("v3 mf8 no split", {"gemm": 9, "gemm_split": 0, "gemm_mf": 8}),
              ("v3 mf8 FORCED split", {"gemm": 9, "gemm_split": 1, "gemm_mf": 8}), ("v3 mf7 FORCED split", {"gemm": 9, "gemm_split": 1, "gemm_mf": 7})]
