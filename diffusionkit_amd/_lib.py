@@ -81,6 +81,7 @@ class dk_gemm_fp8_desc(C.Structure):
         ("gate_seg_len", C.c_int32), ("gate_stride", C.c_int32),
         ("epilogue", C.c_int32), ("c_mx8", C.c_int32),
         ("C_scales", C.c_void_p), ("c_rows", C.c_int32), ("c_row0", C.c_int32), ("c_col0", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 

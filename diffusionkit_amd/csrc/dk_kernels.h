@@ -129,6 +129,10 @@ struct GemmF8Params {
   float kn_eps;
   const bf16_t* qn_w;  // ... and of the query columns [qn_col0, qn_col1) (see GemmParams)
   int qn_col0, qn_col1;
+  // optional K-split scratch (dk_gemm_split_workspace_bytes(), the bf16 kernels' buffer: fp32 slabs + flags, flag region zero between launches):
+  // round 6 -- a launch of at most half a round of tiles with a long reduction is cut along K (FLUX below 1024 x 1024)
+  void* workspace;
+  size_t workspace_bytes;
 };
 bool dk_gemm256f8_eligible(const GemmF8Params& p);
 int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream_t stream);

@@ -219,6 +219,7 @@ extern "C" int dk_gemm_fp8(const dk_gemm_fp8_desc* d, void* stream) {
     DK_REQUIRE(d->M % 256 == 0 && d->c_col0 % 32 == 0 && d->C_scales != nullptr, "MX-fp8 output: M a multiple of 256, column offset a multiple of 32");
     p.SC = (unsigned char*)d->C_scales; p.sc_nblk = mx_nblk(d->c_rows); p.c_row0 = d->c_row0; p.sc_kb0 = d->c_col0 / 32;
   }
+  p.workspace = d->workspace; p.workspace_bytes = d->workspace_bytes;
   return dk_launch_gemm256f8(p, nullptr, S_(stream));
 }
 static Mx8Out mx8_out(void* out, void* scales, int ldo, long rows, int row0, int seg_len, int seg_stride, int col0) {
@@ -822,6 +823,7 @@ static GemmF8Params f8_params(const dk_mmdit* m, const unsigned char* abuf, cons
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
   p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride; p.a_row0 = a_row0; p.sa_nblk = m->nblk;
   p.epi = epi;
+  if (g_linear_ws) { p.workspace = g_linear_ws; p.workspace_bytes = dk_gemm_split_workspace_bytes(); }  // (the K split of small launches, round 6)
   return p;
 }
 static void f8_out_bf16(GemmF8Params& p, bf16_t* C, int ldc, int c_seg_len, int c_seg_stride) {

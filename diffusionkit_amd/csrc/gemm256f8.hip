@@ -69,7 +69,19 @@ __device__ __forceinline__ int f8_xcd_contiguous(int bid, int count) {
   return start + (bid >> 3);
 }
 
-__global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, GemmF8Params pb, int tiles_a, int tiles_b) {
+// K split of a launch that is at most half a round of tiles (round 6; gemm256v3.hip's SplitArgs for the all-remainder case): every tile is cut into S
+// equal K ranges, piece 0 = [0, ks) is the tile's finisher, pieces 1 .. S-1 share [ks, nk) and are producers (raw fp32 accumulators -> slab, flag).
+// Block order = dispatch order: the finishers first, then the producers; tiles * S <= #CU, so every workgroup is resident and a finisher's wait ends.
+struct F8Split {
+  float* slabs;     // [tiles * (S - 1)][512 threads x 32 accumulator quads] fp32, thread-linear (16 bytes per thread and quad: coalesced)
+  unsigned* flags;  // [tiles * (S - 1)], zero between launches (reset by the finisher)
+  unsigned* error_word;
+  int S;            // pieces per tile (0 / 1: no split)
+  int ks;           // K-tiles of the finisher piece
+};
+#define F8_SLAB_FLOATS (256 * 256)
+
+__global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, GemmF8Params pb, int tiles_a, int tiles_b, F8Split sp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((unsigned)(size_t)(lds_char*)smem != 0u) __builtin_trap();  // the LDS image is addressed from 0
   const int tid = threadIdx.x;
@@ -78,7 +90,9 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, q = lane >> 4;
 
-  const int tile = f8_xcd_contiguous(blockIdx.x, tiles_a + tiles_b);
+  const int n_tiles = tiles_a + tiles_b;
+  const int piece = sp.S > 1 ? (int)blockIdx.x / n_tiles : -1;  // -1 whole tile, 0 finisher, >= 1 producer
+  const int tile = f8_xcd_contiguous(sp.S > 1 ? (int)blockIdx.x - piece * n_tiles : (int)blockIdx.x, n_tiles);
   const bool second = tile >= tiles_a;
   // ONE scalar base into the kernel-argument segment for this tile's parameter block (round 4; gemm256v3.hip).  Written as
   // `second ? pb : pa` the compiler kept both blocks' M .. c_seg_len in SCRATCH and read them back with dynamically indexed scratch_load_dword
@@ -103,7 +117,15 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const int p_sa_nblk = p.sa_nblk;
   const int p_c_seg_len = p.c_seg_len;
   const int tl = second ? tile - tiles_a : tile;
-  const int nk = p_K / BKB;
+  const int nk_full = p_K / BKB;
+  int k0 = 0, nk = nk_full;  // this workgroup's K-tile range [k0, k0 + nk)
+  if (piece == 0) {
+    nk = sp.ks;
+  } else if (piece > 0) {
+    const int rest = nk_full - sp.ks, np = sp.S - 1;
+    k0 = sp.ks + rest * (piece - 1) / np;
+    nk = sp.ks + rest * piece / np - k0;
+  }
   const int nbm = (p_M + T256 - 1) / T256, nbn = p_N / T256;
 
   // lane-constant parts of the LDS fragment addresses: row l15 (+ 16 * fragment), read j = position (4 j + q) ^ swz(row)
@@ -136,8 +158,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
       la[hh][j] = phys * (unsigned)p_lda + chunk * 16;
     }
   }
-  const char* gA = (const char*)p.A;
-  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p_ldw;
+  const char* gA = (const char*)p.A + (size_t)k0 * BKB;
+  const char* gW = (const char*)p.W + ((size_t)n0 + wave * 16) * (size_t)p_ldw + (size_t)k0 * BKB;
   const size_t w128 = (size_t)128 * p_ldw, w8 = (size_t)8 * p_ldw;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)gW, 0, -1, 0x00020000);
@@ -161,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
   const int mrow0 = m0 + wm * 128;
   const int mrow_sc = min(mrow0, (p_M - 1) & ~127);
   const unsigned a_blk = (unsigned)(((mrow_sc / p_a_seg_len) * p_a_seg_stride + (mrow_sc % p_a_seg_len) + p_a_row0) >> 7);
-  const unsigned char* sa_ptr = p.SA + ((size_t)a_blk * 64 + lane) * 8;
   const size_t sa_step = (size_t)p_sa_nblk * 512;  // bytes between K-tiles
+  const unsigned char* sa_ptr = p.SA + ((size_t)a_blk * 64 + lane) * 8 + (size_t)k0 * sa_step;
   u32x2 sa_cur, sa_nxt;
 
   f32x4 acc[4][8];  // [nf][mf]
@@ -350,6 +372,53 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256f8_kernel(GemmF8Params pa, G
 #undef F8_ITER
 #undef F8_DRAIN
 #undef F8_DRIVE
+
+  // ---------------- K split: producers hand their raw accumulators to the tile's finisher (gemm256v3.hip's protocol: write-through slab stores,
+  // vmcnt(0) in every wave, barrier, one relaxed agent-scope flag store; finisher: relaxed poll, one agent-scope acquire, barrier, plain loads).
+  // The MX scales were applied inside the MFMAs, the weight scale and the bias are applied once, by the finisher's tail: partial sums simply add.
+  if (piece >= 0) {
+    const int n_prod = sp.S - 1;
+    if (piece >= 1) {
+      float* const slab = sp.slabs + (size_t)(tile * n_prod + piece - 1) * F8_SLAB_FLOATS + (size_t)tid * 4;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slab + (size_t)(nf * 8 + mf) * 2048), "v"(acc[nf][mf]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(sp.flags + tile * n_prod + piece - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      for (int pp = 0; pp < n_prod; ++pp) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sp.flags + tile * n_prod + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 24)) {
+            __hip_atomic_store(sp.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    for (int pp = 0; pp < n_prod; ++pp) {
+      const float* const slab = sp.slabs + (size_t)(tile * n_prod + pp) * F8_SLAB_FLOATS + (size_t)tid * 4;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) {
+          const f32x4 o = *(const f32x4*)(slab + (size_t)(nf * 8 + mf) * 2048);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nf][mf][e] += o[e];
+        }
+    }
+    __syncthreads();  // every wave has read the slabs
+    if (tid == 0)
+      for (int pp = 0; pp < n_prod; ++pp) __hip_atomic_store(sp.flags + tile * n_prod + pp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
   // All waves passed the last loop barrier after their final ds_read of live data, so the ring is free.
@@ -652,10 +721,32 @@ int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream
   }
   const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
   const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;
+  // K split (round 6): a launch of at most half a round of tiles whose reduction is long enough -- the bf16 rule (gemm256v3.hip: plan_split, measured
+  // break-even at 48 saved K-tile steps; an fp8 K-tile of 128 elements takes as long as a bf16 one of 64) -- FLUX's fc2 / linear2 below 1024 x 1024.
+  // Never with the fused key QKNorm (a cut tile's finisher has no second pass over its row sums) and never without the caller's workspace.
+  F8Split sp;
+  memset(&sp, 0, sizeof(sp));
+  {
+    const int n_cu = dk_device_cu_count(), G = n_cu & ~7, tiles = tiles_a + tiles_b, nk = p.K / BKB;
+    const bool have_ws = p.workspace != nullptr && p.workspace_bytes >= dk_gemm_split_workspace_bytes() && ((uintptr_t)p.workspace & 255) == 0 &&
+                         p.kn_w == nullptr && (p2 == nullptr || p2->kn_w == nullptr);
+    if (have_ws && g_dk_v3_split != 0 && tiles > 0 && tiles * 2 <= G) {
+      const int S = G / tiles < 4 ? G / tiles : 4;
+      const int ks = (nk + S - 1) / S;
+      const int min_saved = g_dk_v3_split > 0 ? 1 : (g_dk_v3_split_min >= 0 ? g_dk_v3_split_min : 48);
+      if (S >= 2 && nk - ks >= S - 1 && nk - ks >= min_saved && tiles * (S - 1) <= 256) {
+        sp.S = S; sp.ks = ks;
+        sp.slabs = (float*)p.workspace;
+        sp.flags = (unsigned*)((char*)p.workspace + (size_t)256 * F8_SLAB_FLOATS * 4);
+        sp.error_word = sp.flags + 512;
+      }
+    }
+  }
+  const int grid = (tiles_a + tiles_b) * (sp.S > 1 ? sp.S : 1);
   double work = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   if (p2) work += 2.0 * (double)p2->M * (double)p2->N * (double)p2->K;
   dk_prof_begin(3, work, stream);
-  hipLaunchKernelGGL(dk_gemm256f8_kernel, dim3(tiles_a + tiles_b), dim3(512), LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b);
+  hipLaunchKernelGGL(dk_gemm256f8_kernel, dim3(grid), dim3(512), LDS_BYTES, stream, p, p2 ? *p2 : p, tiles_a, tiles_b, sp);
   dk_prof_end(stream);
   DK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -309,9 +309,10 @@ def ln_modulate_mx8(x: Tensor, shift: Tensor, scale: Tensor, mod_seg_len: int = 
 
 def gemm_fp8(a8: Tensor, a_scales: Tensor, w8: Tensor, w_scale: Tensor, bias: Optional[Tensor] = None, epilogue: int = DK_EPI_BIAS,
              gate: Optional[Tensor] = None, res: Optional[Tensor] = None, gate_seg_len: int = 0, M: Optional[int] = None,
-             k: Optional[int] = None, out_mx8: bool = False):
+             k: Optional[int] = None, out_mx8: bool = False, workspace: Optional[Tensor] = None):
     """dk_gemm_fp8 over the first M rows / k columns of an MX-fp8 activation buffer a8 [rows, lda] and an e4m3 weight w8 [N, ldw].
-    Returns bf16 [M, N], or with ``out_mx8`` (e4m3 bytes [M, N], scale side array)."""
+    Returns bf16 [M, N], or with ``out_mx8`` (e4m3 bytes [M, N], scale side array).  ``workspace`` (ops.gemm_workspace): lets a launch of at most
+    half a round of tiles with a long reduction be cut along K, as the engines do."""
     lib = _lib.load()
     for n, t, dt in (("a8", a8, torch.uint8), ("a_scales", a_scales, torch.uint8), ("w8", w8, torch.uint8), ("w_scale", w_scale, torch.float32)):
         _require_cuda(t, n, dt)
@@ -328,6 +329,8 @@ def gemm_fp8(a8: Tensor, a_scales: Tensor, w8: Tensor, w_scale: Tensor, bias: Op
     d.gate_seg_len = gate_seg_len
     d.gate_stride = gate.stride(0) if gate is not None else 0
     d.epilogue = epilogue
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel()
     if out_mx8:
         out = torch.zeros(M, N, dtype=torch.uint8, device=a8.device)
         sc = torch.zeros(mx_scale_bytes(M, N), dtype=torch.uint8, device=a8.device)

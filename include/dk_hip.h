@@ -219,6 +219,10 @@ typedef struct dk_gemm_fp8_desc {
   int32_t c_mx8;        /* 1: MX-fp8 output (M % 256 == 0)                                                               */
   void* C_scales;
   int32_t c_rows, c_row0, c_col0; /* rows of the output buffer, physical row / column (multiple of 32) that C points at  */
+  /* ABI 5: optional K-split scratch, the same buffer and rules as dk_gemm_desc.workspace (dk_gemm_workspace_bytes() bytes, 256-byte aligned, last
+   * 4096 bytes zero before the first use): a launch of at most half a round of 256 x 256 tiles with a long reduction is cut along K.  NULL: never. */
+  void* workspace;
+  size_t workspace_bytes;
 } dk_gemm_fp8_desc;
 int dk_gemm_fp8(const dk_gemm_fp8_desc* d, void* stream);
 size_t dk_mx_scale_bytes(int64_t rows, int32_t k);

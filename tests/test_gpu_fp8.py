@@ -93,6 +93,36 @@ def test_gemm_fp8_bias(dev, M, N, K):
     assert rel_l2(ref, out.float()) < TOL_SINGLE_OP, rel_l2(ref, out.float())
 
 
+@pytest.mark.parametrize("M,N,K,split", [(1280, 3072, 12288, True),    # FLUX 512 x 512 fc2: 60 tiles, four K ranges each
+                                          (1280, 3072, 15360, True),    # ... linear2
+                                          (2560, 3072, 12288, True),    # 768 x 768: 120 tiles, two K ranges
+                                          (1280, 3072, 3072, False),    # o_proj: below the break-even, stays whole
+                                          (4352, 3072, 12288, False)])  # 1024 x 1024: a round of the CUs, untouched
+def test_gemm_fp8_small_launch_is_split_automatically(dev, M, N, K, split):
+    """Round 6: the fp8 GEMM's K split (gemm256f8.hip: F8Split) -- a launch of at most half a round of 256 x 256 tiles with a long reduction is cut along K
+    when the caller hands in the split workspace, as the engines do (FLUX below 1024 x 1024).  Raw fp32 accumulators are exchanged, so the result is the
+    unsplit one up to the fp32 summation order; against the exact product of the dequantised operands, and against the same launch without the workspace."""
+    a, qa, ea, qw, ws, a_dq, w_dq = _fp8_problem(M, N, K, seed=M + N + K, w_pitch=K + 128 if K >= 8192 else None)
+    bias, gate, res = randn(N, seed=5, scale=0.5), randn(1, N, seed=6), randn(M, N, seed=7)
+    rows = (M + 127) // 128 * 128
+    a8 = torch.zeros(rows, K, dtype=torch.uint8)
+    a8[:M] = qa
+    wsp = ops.gemm_workspace(dev)
+    args = (a8.to(dev), f8.scales_to_array(ea, rows).to(dev), qw.to(dev), ws.to(dev))
+    kw = dict(bias=bias.to(dev, BF), epilogue=DK_EPI_GATE_RES, gate=gate.to(dev, BF), res=res.to(dev, BF), gate_seg_len=M, M=M, k=K)
+    y = ops.gemm_fp8(*args, workspace=wsp, **kw)
+    y0 = ops.gemm_fp8(*args, **kw)
+    lin = bf16r(a_dq @ w_dq.t() + bias)
+    ref = res + bf16r(gate * lin)
+    assert rel_l2(ref, y.float()) < TOL_SINGLE_OP and rel_l2(ref, y0.float()) < TOL_SINGLE_OP
+    if split:
+        assert not torch.equal(y0, y), "the launch was expected to be cut along K (other summation order)"
+        assert float((y0.float() != y.float()).float().mean()) < 0.05
+    else:
+        assert torch.equal(y0, y)
+    assert int(wsp[-4096:].sum()) == 0  # the flag region (and the error word) is left zero
+
+
 def test_gemm_fp8_gate_res(dev):
     M, N, K, S = 512, 256, 256, 256
     a, qa, ea, qw, ws, a_dq, w_dq = _fp8_problem(M, N, K, seed=21)
