@@ -40,6 +40,7 @@ Round 5 (VERDICT r4 "Next round" item 2: CLOSED-LOOP runs of the 50-step configu
   flux_dev_10    BASELINE configs[3]'s shape closed loop: 19 + 38 blocks at FLUX width, S_t = 512, a complete 10-step schedule
                  (sigma 1 -> 0) -> the latent after steps 1, 2, 5 (fp16) and 10 (fp32); replayed with bf16 and with fp8 weights
 
+Round 6: flux_768 -- the same at 768 x 768 (latent 96 x 96, S = 2560: the two-range K split and the one-round attention5 launch), fp32 oracle
 Round 6: flux_512 -- FLUX.1-schnell, all 57 blocks, 4 Euler steps at 512 x 512 (latent 64 x 64, S = 1280: the reference CLI's default resolution) -> final
                  latent, fp32 oracle + the bf16-emulating one
 Round 6 (VERDICT r5 missing 9): sd35_full -- SD3.5-large (38 blocks, width 2432, QK-norm) at full depth, B = 2, CFG 5.0, steps 1 and 50 of the
@@ -142,6 +143,7 @@ SD35_FULL = dict(cfg=SD3_8b, seed_w=1234, latent=(128, 128), S_t=589, steps_of=5
 # ---- round 6 case: FLUX.1-schnell end to end at the resolution the reference's CLI defaults to (generate_images.py:15-30): latent 64 x 64, S = 1280 --
 # the launches the round's small-launch rules changed (fc2 / linear2 cut along K inside the model)
 FLUX_512 = dict(FLUX_FULL, latent=(64, 64))
+FLUX_768 = dict(FLUX_FULL, latent=(96, 96))   # S = 256 + 2304 = 2560: 120-tile launches cut in TWO K ranges, attention5 in one round of 240 blocks
 
 
 # ---- round 6 case: configs[3]'s shape closed loop at its STATED length ---------------------------------------------
@@ -558,7 +560,8 @@ CASES = {"sd3_fp16_context": make_sd3_fp16_context, "flux_dev_50": lambda: make_
          "flux_dev_full": lambda: make_forced(FLUX_DEV_FULL, "flux_dev_full", True),
          "sd3_full_late": lambda: make_forced(SD3_FULL_LATE, "sd3_full_late", True),
          "sd35_full": lambda: make_forced(SD35_FULL, "sd35_full", False),  # (fp32 oracle only: the bf16-emulating pass on 8 B parameters ran this 62 GB host out of memory)
-         "flux_512": lambda: make_flux_full(True, FLUX_512, "flux_512")}
+         "flux_512": lambda: make_flux_full(True, FLUX_512, "flux_512"),
+         "flux_768": lambda: make_flux_full(False, FLUX_768, "flux_768")}
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("DK_FIXTURE_THREADS", os.cpu_count() or 8)))
