@@ -481,6 +481,64 @@ __global__ __launch_bounds__(512, 2) void dk_gemm256v3_kernel(GemmParams pa, Gem
 #undef DK_DRIVE
 #undef DK_ROTATE_W
 
+  // ---------------- K split, round 6: the pieces of a cut tile exchange their RAW accumulators (registers -> slab -> registers) ----------------
+  // Until round 6 a cut tile went through a second tail: fp32 staging images (two passes over the LDS), row-major fp32 slabs written from the read-back,
+  // the finisher adding them row by row inside its epilogue loop.  The accumulators are in registers on both sides: a producer now stores them as they are
+  // (thread-linear: one coalesced 16-byte write-through store per thread and accumulator quad), the finisher adds them in front of the ordinary
+  // whole-tile tail (bias before staging, bf16 image, one LDS round trip) -- gemm256f8.hip's exchange, which was written first.  Same hand-off protocol
+  // (guide G16): write-through stores, vmcnt(0) in every wave, barrier, one relaxed agent-scope flag store; finisher: relaxed poll, one agent-scope
+  // acquire, barrier, plain loads.  Summation order of a cut tile: finisher's K range first, then the producers' in piece order (as before).
+  // (Linears only: the conv form of the 256-row kernel sits at exactly 256 registers and keeps the fp32-image path below -- this block cost it 7 spills)
+  if (!CONV && piece >= 0) {
+    const int n_prod_x = sp.S - 1;
+    // (thread index from a FRESH lane id + the scalar wave id: a value carried across the K loop costs a register there -- the conv form of the
+    //  256-row kernel has none to spare)
+    int lane_x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_x));
+    const unsigned toff = (unsigned)(wave * 64 + lane_x) * 4u;  // floats
+    if (piece >= 1) {
+      float* const slab = sp.slabs + (size_t)(rt * n_prod_x + piece - 1) * SLAB_FLOATS;  // (uniform base: scalar registers)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) v3_store_sc1_b128(slab + (size_t)(nf * 8 + mf) * 2048 + toff, acc[nf][mf]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have completed
+      __syncthreads();
+      if (wave == 0 && lane_x == 0) __hip_atomic_store(sp.flags + rt * n_prod_x + piece - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (wave == 0 && lane_x == 0) {
+      for (int pp = 0; pp < n_prod_x; ++pp) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sp.flags + rt * n_prod_x + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 24)) {
+            __hip_atomic_store(sp.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    for (int pp = 0; pp < n_prod_x; ++pp) {
+      const float* const slab = sp.slabs + (size_t)(rt * n_prod_x + pp) * SLAB_FLOATS;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const f32x4 o = *(const f32x4*)(slab + (size_t)(nf * 8 + mf) * 2048 + toff);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nf][mf][e] += o[e];
+        }
+    }
+    __syncthreads();  // every wave has read the slabs
+    if (wave == 0 && lane_x == 0)
+      for (int pp = 0; pp < n_prod_x; ++pp) __hip_atomic_store(sp.flags + rt * n_prod_x + pp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    piece = -1;  // from here on the finisher is a whole tile
+  }
+  if (!CONV) __builtin_assume(piece < 0);  // (no Linear tile reaches the fp32-image tail path below any more; convolutions still do)
+
   // ---------------- tail: accumulators -> LDS (wave-private image) -> row-major ----------------
   // All waves passed the last loop barrier after their final ds_read, so the ring is free.
   const bool out2 = p.n_split > 0 && n0 >= p.n_split;  // tile-uniform: second output of a column-split GEMM
