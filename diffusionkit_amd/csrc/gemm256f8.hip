@@ -722,7 +722,7 @@ int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream
   const int tiles_a = ((p.M + T256 - 1) / T256) * (p.N / T256);
   const int tiles_b = p2 ? ((p2->M + T256 - 1) / T256) * (p2->N / T256) : 0;
   // K split (round 6): a launch of at most half a round of tiles whose reduction is long enough -- the bf16 rule (gemm256v3.hip: plan_split, measured
-  // break-even at 48 saved K-tile steps; an fp8 K-tile of 128 elements takes as long as a bf16 one of 64) -- FLUX's fc2 / linear2 below 1024 x 1024.
+  // break-even around 32 saved K-tile steps; an fp8 K-tile of 128 elements takes as long as a bf16 one of 64) -- FLUX's fc2 / linear2 below 1024 x 1024.
   // Never with the fused key QKNorm (a cut tile's finisher has no second pass over its row sums) and never without the caller's workspace.
   F8Split sp;
   memset(&sp, 0, sizeof(sp));
@@ -733,7 +733,7 @@ int dk_launch_gemm256f8(const GemmF8Params& p, const GemmF8Params* p2, hipStream
     if (have_ws && g_dk_v3_split != 0 && tiles > 0 && tiles * 2 <= G) {
       const int S = G / tiles < 4 ? G / tiles : 4;
       const int ks = (nk + S - 1) / S;
-      const int min_saved = g_dk_v3_split > 0 ? 1 : (g_dk_v3_split_min >= 0 ? g_dk_v3_split_min : 48);
+      const int min_saved = g_dk_v3_split > 0 ? 1 : (g_dk_v3_split_min >= 0 ? g_dk_v3_split_min : 32);
       if (S >= 2 && nk - ks >= S - 1 && nk - ks >= min_saved && tiles * (S - 1) <= 256) {
         sp.S = S; sp.ks = ks;
         sp.slabs = (float*)p.workspace;

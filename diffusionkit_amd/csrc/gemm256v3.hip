@@ -915,7 +915,7 @@ bool dk_gemm256v3_eligible(const GemmParams& p) {
 // than when 192 are, so a remainder of MORE than half the CUs (finisher + several producer pieces in turn on the
 // spare CUs) loses on every shape but the longest-K one and is only taken when forced.
 int g_dk_v3_split = -1;
-int g_dk_v3_split_min = -1;  // dk_tune_set("gemm_split_min", v): saved K-tile steps below which a Linear that is ALL remainder stays whole; -1: 48 (see plan_split)
+int g_dk_v3_split_min = -1;  // dk_tune_set("gemm_split_min", v): saved K-tile steps below which a Linear that is ALL remainder stays whole; -1: 32 (see plan_split)
 
 // 256 fp32 tile images + 4 KiB of flags (and the error word)
 size_t dk_gemm_split_workspace_bytes() { return (size_t)256 * SLAB_FLOATS * 4 + 4096; }
@@ -948,10 +948,10 @@ static SplitPlan plan_split(int tiles, int nk, bool have_ws, int n_cu, bool line
   // a K-tile step costs about 1.45 us; splitting costs a slab write + read and a flag round trip per tile
   if (g_dk_v3_split < 0 && (nk - t_steps) * 1.45 < 25.0) return none;
   // a Linear that is ALL remainder (round 6: FLUX / SD3 below 1024 x 1024, 60 - 120 tiles): every tile pays S - 1 slab round trips at once, and the few
-  // busy CUs run their K-tiles in ~1 us.  Measured (profiles/r06_gemm_small_m.log): FLUX's o_proj at 512 x 512 (K = 3072, four ranges: 36 steps saved)
-  // loses 16 us with the split, fc2 / linear2 (144 / 180 saved) gain 60 - 90; in the model (scripts/split_min_sweep.sh) SD3-medium 512 x 512 wants its
-  // fc2 cut (K = 6144, three ranges: 64 saved; 8.32 against 8.57 ms per step), FLUX 512 x 512 is flat from 40 to 80 and loses 2 % at 0
-  if (g_dk_v3_split < 0 && linear && tiles < G && nk - t_steps < (g_dk_v3_split_min >= 0 ? g_dk_v3_split_min : 48)) return none;
+  // busy CUs run their K-tiles in ~1 us.  Measured (profiles/r06_gemm_small_m.log, r06_res_sweep.md): with the fp32-image exchange of rounds 1-5 FLUX's o_proj at
+  // 512 x 512 (K = 3072, four ranges: 36 steps saved) lost 16 us with the split and fc2 / linear2 (144 / 180 saved) gained 60 - 90; with the raw-accumulator
+  // exchange (above, round 6) the in-model sweep is flat from 0 to 48 saved steps and 1 % better at 24 - 36 than at 48: the rule cuts from 32
+  if (g_dk_v3_split < 0 && linear && tiles < G && nk - t_steps < (g_dk_v3_split_min >= 0 ? g_dk_v3_split_min : 32)) return none;
   return SplitPlan{tiles - T, T, S, ks};
 }
 

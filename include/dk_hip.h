@@ -415,7 +415,7 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
  * (asm body) on every shape IT accepts; "gemm_v4": 0 = the automatic choice never takes the latter; "gemm_skew": start skew of that kernel's
  * multi-round launches in 0.25 us steps (-1: none); "gemm_mf": 8 / 7 = 256- / 224-row
  * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_split_min": K-tile steps a workgroup must save before a
- * Linear of at most half a round of tiles is cut along K as a whole (default 48); "gemm_pair_nk": K-tile steps from which an image + text pair with
+ * Linear of at most half a round of tiles is cut along K as a whole (default 32); "gemm_pair_nk": K-tile steps from which an image + text pair with
  * a small extra round is grouped and cut (default 32); "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
  * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise; 10 one-wave-per-SIMD kernel with the generated asm

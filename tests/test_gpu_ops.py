@@ -379,7 +379,8 @@ def test_gemm_v3_remainder_split(dev, M, N, K, epi, mf):
 @pytest.mark.parametrize("M,N,K,epi,split", [(1280, 3072, 12288, "gate_res", True),   # FLUX 512 x 512 fc2: 60 tiles of 256 rows, four K ranges each
                                               (1280, 3072, 15360, "gate_res", True),   # ... linear2
                                               (2560, 3072, 12288, "bias", True),       # 768 x 768: 120 tiles, two K ranges
-                                              (1280, 3072, 3072, "gate_res", False),   # o_proj: below the break-even, stays whole
+                                              (1280, 3072, 3072, "gate_res", True),    # o_proj at 512 x 512: 36 K-tile steps saved per workgroup, just above the break-even (32)
+                                              (2560, 3072, 3072, "gate_res", False),   # ... at 768 x 768 (two ranges: 24 saved): below it, stays whole
                                               (4352, 3072, 12288, "gate_res", False)])  # 1024 x 1024: a full round, untouched
 def test_gemm_small_launch_is_split_automatically(dev, M, N, K, epi, split):
     """Round 6 (the reference CLI's 512 x 512 default, generate_images.py:15-30): a block Linear of at most half a round of 256 x 256 tiles is cut
