@@ -239,7 +239,7 @@ thread_local DkGemmPlan* g_dk_gemm_plan = nullptr;
 // (profiles/r05_gemm_v4_*.log: 8192^3 1587 against 1488 TF with cold weights, the model's linear1 / linear2 / fc1 / fc2 +4-5 %), but has no
 // remainder handling: gemm256v3.hip keeps the launches whose last round of the CUs is a small remainder (its 224-row tiles and the
 // remainder-wave K split fill those: the q / k / v projections at 2.25-2.4 rounds, the grouped image + text fc1 at 3.2).
-int g_dk_pair_split_nk = -1;  // dk_tune_set("gemm_pair_nk", v): K-tile steps from which an image + text pair whose extra round is a small remainder is grouped and cut along K; -1: 32
+int g_dk_pair_split_nk = -1;  // dk_tune_set("gemm_pair_nk", v): K-tile steps from which an image + text pair whose extra round is a small remainder is grouped and cut along K; -1: 24 (32 until the raw-accumulator exchange of round 6: profiles/r06_gemm_pair_nk.log)
 int g_dk_v4_auto = -1;  // dk_tune_set("gemm_v4", v): -1 (default) the rule below, 0 never in the automatic choice (A/B runs)
 static bool dk_use_v4(const GemmParams& a, const GemmParams* b) {
   if (g_dk_gemm_mode != 10 && (g_dk_gemm_mode != -1 || g_dk_v4_auto == 0)) return false;
@@ -359,7 +359,7 @@ int dk_launch_gemm_pair(const GemmParams& a_in, const GemmParams& b_in, hipStrea
     const long ta = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tb = (long)((b.M + 255) / 256) * ((b.N + 255) / 256);
     const long n_cu = dk_device_cu_count();  // (rounds in units of THIS device's CUs; the fractions below were fitted on 256)
     // ... unless the kernel can cut that extra, small wave along K (remainder-wave split, needs the workspace)
-    const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % n_cu <= n_cu / 4 && a.K / 64 >= (g_dk_pair_split_nk >= 0 ? g_dk_pair_split_nk : 32);
+    const bool split_ok = g_dk_v3_split != 0 && a.workspace != nullptr && (ta + tb) % n_cu <= n_cu / 4 && a.K / 64 >= (g_dk_pair_split_nk >= 0 ? g_dk_pair_split_nk : 24);
     // (gemm256v4.hip: the same test at ITS tile height -- with 224-row tiles the image + text fc1 of FLUX is 912 + 96 tiles: both 4 rounds)
     if (dk_gemm256v4_eligible(a) && dk_gemm256v4_eligible(b)) {
       const int bm4 = 32 * dk_gemm256v4_pick_mf(a, &b, (int)n_cu);

@@ -416,7 +416,7 @@ int dk_profile_read(int32_t kernel_class, double* total_ms, double* total_flops,
  * multi-round launches in 0.25 us steps (-1: none); "gemm_mf": 8 / 7 = 256- / 224-row
  * tiles; "gemm_split": 0 / 1 = remainder-wave K split never / whenever possible; "gemm_split_min": K-tile steps a workgroup must save before a
  * Linear of at most half a round of tiles is cut along K as a whole (default 32); "gemm_pair_nk": K-tile steps from which an image + text pair with
- * a small extra round is grouped and cut (default 32); "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
+ * a small extra round is grouped and cut (default 24); "gemm_fuse_k" / "gemm_fuse_q": 0 / 1 = the keys' /
  * queries' QKNorm + RoPE in the q/k/v projection's tail off / on; "attn": kernel of dk_attention_bf16 (4 lean kernel,
  * 9 phase-alternating kernel: head_dim 128 only, falls back to 4 otherwise; 10 one-wave-per-SIMD kernel with the generated asm
  * tile loop: head_dim 128, S a multiple of 256 and >= 768, falls back to 9 otherwise -- the automatic choice from S = 2048 on, and from
